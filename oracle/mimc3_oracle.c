@@ -1,0 +1,421 @@
+/*
+ * oracle/mimc3_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the MIMC3 hot path, written from
+ * the reference's behaviour, flat arrays instead of GMA structs.  It is the checker for the HIP
+ * path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product library (mimc3_amd/csrc) never links, imports or falls back to anything in oracle/.
+ *
+ * PINNING: this file is verified bit-for-bit against the compiled reference itself
+ * (oracle/_ref/libmimc3_ref.so, built by oracle/Makefile from the sources under /root/reference)
+ * in tests/test_oracle_vs_ref.py, and against the committed golden vectors that the same
+ * reference build produced (tests/golden/, tests/test_oracle_golden.py).
+ *
+ * Arithmetic notes (all deliberate, all mirrored by the HIP kernels):
+ *  - products of two f32 pixels are rounded to f32 first, then accumulated in f64, in the
+ *    reference's loop order (u outer, v inner)                          MIMC_module.c:719-733
+ *  - the NCC formula is evaluated in f64 and stored as f32               MIMC_module.c:734
+ *  - the 3x3 fit coefficients are f32 expressions assigned to f64        MIMC_module.c:769-780
+ *  - the peak offsets are stored to f32 after every step                 MIMC_module.c:783-788
+ *  - build with -ffp-contract=off: the reference binary (x86-64 baseline, no FMA) never fuses.
+ *
+ * Defined-where-the-reference-is-undefined (documented in DESIGN.md):
+ *  T4  last row/column of the search window are 0.0 (reference: never written, :869-886)
+ *  T7  QM: a NaN fit / empty candidate list leaves the point unchanged (reference: compares
+ *      stale or uninitialised stack variables, :2165-2193)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MIN_DN 0.0000000001 /* MIMC_module.c:21, a double constant compared against f32 pixels */
+
+/* =========================================================================================
+ * a2  DLC pivots                                                   MIMC_module.c:543-602
+ * ======================================================================================= */
+static int32_t pivots_for_point(const double *row, float dt, float mpp, float aw_sf, float aw_cre,
+                                int32_t ocw, int32_t H, int32_t W, int32_t *uv /* may be NULL */)
+{
+    float u = 0.0f, v = 0.0f, incr_u, incr_v, norm_incr, theta;
+    double length_pivot;
+    theta = atan2(row[5], row[4]);                       /* :559  f64 -> f32 */
+    incr_u = cos(theta);                                 /* :560  cos((double)theta) -> f32 */
+    incr_v = sin(theta);
+    if (fabs(incr_u) > fabs(incr_v)) {                   /* :562-571, incr_u is normalised FIRST */
+        incr_u = incr_u / fabs(incr_u);
+        incr_v = incr_v / fabs(incr_u);
+    } else {
+        incr_u = incr_u / fabs(incr_v);
+        incr_v = incr_v / fabs(incr_v);
+    }
+    norm_incr = sqrt(incr_u * incr_u + incr_v * incr_v); /* f32 expression, f64 sqrt, -> f32 */
+    length_pivot = sqrt(row[4] * row[4] + row[5] * row[5]) / mpp / 365 * dt * aw_sf + aw_cre + 1;
+    int32_t n = 0;
+    while (u + (float)row[2] - (float)ocw > 0 && u + (float)row[2] + (float)ocw < (float)(W - 1) &&
+           v + (float)row[3] - (float)ocw > 0 && v + (float)row[3] + (float)ocw < (float)(H - 1) &&
+           length_pivot > (double)(norm_incr * (double)n)) {
+        n++;
+        u += incr_u;
+        v += incr_v;
+    }
+    if (uv && n > 0) {
+        u = 0.0f; v = 0.0f;
+        uv[0] = 0; uv[1] = 0;
+        for (int32_t k = 1; k < n; k++) {
+            u += incr_u;
+            v += incr_v;
+            uv[2 * k + 0] = (int32_t)(u + 0.5);          /* f64 add, truncation toward zero */
+            uv[2 * k + 1] = -(int32_t)(v + 0.5);
+        }
+    }
+    return n;
+}
+
+/* Returns total pivots; -1 if cap (pairs) too small; -2 if some point has zero pivots. */
+int64_t orc_get_uv_pivot(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf,
+                         float aw_cre, int32_t ocw, int32_t H, int32_t W,
+                         int64_t *piv_off, int32_t *piv_uv, int64_t cap)
+{
+    int64_t tot = 0;
+    int bad = 0;
+    piv_off[0] = 0;
+    for (int32_t g = 0; g < N; g++) {
+        int32_t n = pivots_for_point(xyuvav + 6 * (size_t)g, dt, mpp, aw_sf, aw_cre, ocw, H, W, NULL);
+        if (n <= 0) { bad = 1; n = 0; }
+        tot += n;
+        piv_off[g + 1] = tot;
+    }
+    if (bad) return -2;
+    if (tot > cap) return -1;
+    for (int32_t g = 0; g < N; g++)
+        pivots_for_point(xyuvav + 6 * (size_t)g, dt, mpp, aw_sf, aw_cre, ocw, H, W, piv_uv + 2 * piv_off[g]);
+    return tot;
+}
+
+/* =========================================================================================
+ * a3-a7  matcher                                                   MIMC_module.c:605-890
+ * ======================================================================================= */
+typedef struct {
+    int ocw, cw;          /* chip half width, chip width 2*ocw+1 */
+    int dx2, dy2, Dx2, Dy2;
+    const float *chip;    /* [cw][cw] row-major (v,u) */
+    const float *win;     /* [Dy2][Dx2] */
+    float *cmap;          /* [Dy2][Dx2] */
+} match_ws;
+
+static float ncc_at(const match_ws *w, int pu, int pv)
+{
+    int nsample = 0;
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    const int ocw = w->ocw, cw = w->cw;
+    for (int c3 = -ocw; c3 <= ocw; c3++)                /* u outer  (:719) */
+        for (int c4 = -ocw; c4 <= ocw; c4++) {          /* v inner  (:721) */
+            float a = w->chip[(c4 + ocw) * cw + (c3 + ocw)];
+            float b = w->win[(size_t)(pv + c4) * w->Dx2 + (pu + c3)];
+            if (a >= ORC_MIN_DN && b >= ORC_MIN_DN) {
+                float aa = a * a, bb = b * b, ab = a * b;   /* f32 products (:728-730) */
+                nsample++;
+                sy += b; sx += a; sxx += aa; syy += bb; sxy += ab;
+            }
+        }
+    return (float)((nsample * sxy - sx * sy) /
+                   sqrt((nsample * sxx - sx * sx) * (nsample * syy - sy * sy)));
+}
+
+static void match_point(const float *i0, const float *i1, int32_t H, int32_t W, const double *row,
+                        const int32_t *offset, const int32_t *piv, int32_t npiv, int32_t ocw,
+                        float *out3)
+{
+    const int cw = 2 * ocw + 1;
+    int u0 = (int32_t)row[2], v0 = (int32_t)row[3];     /* T6 truncation (:822-823) */
+    match_ws w;
+    w.ocw = ocw; w.cw = cw;
+    w.dx2 = abs(piv[2 * (npiv - 1) + 0]) + ocw + 2;     /* :863-866 */
+    w.dy2 = abs(piv[2 * (npiv - 1) + 1]) + ocw + 2;
+    w.Dx2 = 2 * w.dx2 + 1; w.Dy2 = 2 * w.dy2 + 1;
+    float *chip = (float *)malloc(sizeof(float) * cw * cw);
+    float *win = (float *)calloc((size_t)w.Dx2 * w.Dy2, sizeof(float));   /* T4: zero-filled */
+    float *cmap = (float *)calloc((size_t)w.Dx2 * w.Dy2, sizeof(float));  /* T4: last row/col 0.0 */
+    /* a4 chip: no bounds check in the reference; caller guarantees the margin (:845-855) */
+    for (int r = 0; r < cw; r++)
+        memcpy(chip + r * cw, i0 + (size_t)(v0 - ocw + r) * W + (u0 - ocw), sizeof(float) * cw);
+    /* a5 window around uv0+offset, zero outside the image, last row/col untouched (:869-886) */
+    int uc = u0 + offset[0], vc = v0 + offset[1];
+    for (int r = 0; r < 2 * w.dy2; r++) {
+        int cv = vc - w.dy2 + r;
+        for (int c = 0; c < 2 * w.dx2; c++) {
+            int cu = uc - w.dx2 + c;
+            win[(size_t)r * w.Dx2 + c] = (cu >= 0 && cu < W && cv >= 0 && cv < H) ? i1[(size_t)cv * W + cu] : 0.0f;
+            cmap[(size_t)r * w.Dx2 + c] = -2.0f;            /* :678-681 */
+        }
+    }
+    w.chip = chip; w.win = win; w.cmap = cmap;
+
+    float uvncc0 = 0.0f, uvncc1 = 0.0f, best = -2.0f;
+    /* a6 validity (:605-644): counts include the zero last row/col of the window */
+    int bad_chip = 0, bad_win = 0;
+    for (int i = 0; i < cw * cw; i++) if (chip[i] < ORC_MIN_DN) bad_chip++;
+    for (int i = 0; i < w.Dx2 * w.Dy2; i++) if (win[i] < ORC_MIN_DN) bad_win++;
+    const float max_ratio = 0.8;
+    if ((float)bad_chip / (float)(cw * cw) > max_ratio || (float)bad_win / (float)(w.Dx2 * w.Dy2) > max_ratio) {
+        const float nanv = sqrt(-1.0);
+        out3[0] = nanv; out3[1] = nanv; out3[2] = -3.0f;
+        free(chip); free(win); free(cmap);
+        return;
+    }
+    int peak_u = w.dx2, peak_v = w.dy2;
+    for (int k = 0; k < npiv; k++) {                    /* a7 hill climb per pivot (:691-753) */
+        int pu = piv[2 * k] + w.dx2, pv = piv[2 * k + 1] + w.dy2;
+        float nccmax = -2.0f;
+        int du = -1, dv = -1, newncc = 1;
+        while ((du != 0 || dv != 0) && newncc != 0) {
+            du = 0; dv = 0;
+            if (pu - ocw <= 1 || pu + ocw >= w.Dx2 - 1 || pv - ocw <= 1 || pv + ocw >= w.Dy2 - 1) break;
+            newncc = 0;
+            for (int c1 = -1; c1 <= 1; c1++)
+                for (int c2 = -1; c2 <= 1; c2++) {
+                    float *cell = &cmap[(size_t)(pv + c2) * w.Dx2 + (pu + c1)];
+                    if (*cell < -1.0) { newncc++; *cell = ncc_at(&w, pu + c1, pv + c2); }
+                    if (*cell > nccmax) { nccmax = *cell; du = c1; dv = c2; }
+                }
+            pu += du; pv += dv;
+        }
+        if (nccmax > best) { peak_u = pu; peak_v = pv; best = nccmax; }
+    }
+    /* 3x3 quadratic fit, f32 expressions widened on assignment (:757-788) */
+    float n9[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) n9[3 * r + c] = cmap[(size_t)(peak_v - 1 + r) * w.Dx2 + (peak_u - 1 + c)];
+    double cp[6];
+    cp[0] = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
+    cp[1] = 9 * n9[0] - 9 * n9[2] - 9 * n9[6] + 9 * n9[8];
+    cp[2] = 6 * n9[0] + 6 * n9[1] + 6 * n9[2] - 12 * n9[3] - 12 * n9[4] - 12 * n9[5] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+    cp[3] = -6 * n9[0] + 6 * n9[2] - 6 * n9[3] + 6 * n9[5] - 6 * n9[6] + 6 * n9[8];
+    cp[4] = -6 * n9[0] - 6 * n9[1] - 6 * n9[2] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+    cp[5] = -4 * n9[0] + 8 * n9[1] - 4 * n9[2] + 8 * n9[3] + 20 * n9[4] + 8 * n9[5] - 4 * n9[6] + 8 * n9[7] - 4 * n9[8];
+    for (int i = 0; i < 6; i++) cp[i] /= 36;
+    uvncc0 = -2 * cp[2] * cp[3] + cp[1] * cp[4];
+    uvncc1 = -2 * cp[0] * cp[4] + cp[1] * cp[3];
+    uvncc0 /= 4 * cp[0] * cp[2] - cp[1] * cp[1];
+    uvncc1 /= 4 * cp[0] * cp[2] - cp[1] * cp[1];
+    uvncc0 += (float)(peak_u - w.dx2);
+    uvncc1 += (float)(peak_v - w.dy2);
+    out3[0] = uvncc0; out3[1] = uvncc1; out3[2] = best;
+    free(chip); free(win); free(cmap);
+}
+
+/* out[N][3] = (du, dv, ncc).  nthreads<=0: OpenMP default.  Returns 0, or -3 on a point whose
+ * chip would leave the image (the reference reads out of bounds there) or has no pivots. */
+int orc_match_ncc_dlc(const float *i0, const float *i1, int32_t H, int32_t W, const double *xyuvav,
+                      int32_t N, const int32_t *offset, const int32_t *piv_uv,
+                      const int64_t *piv_off, int32_t ocw, float *out, int32_t nthreads)
+{
+    for (int32_t g = 0; g < N; g++) {
+        int u0 = (int32_t)xyuvav[6 * (size_t)g + 2], v0 = (int32_t)xyuvav[6 * (size_t)g + 3];
+        if (u0 - ocw < 0 || u0 + ocw >= W || v0 - ocw < 0 || v0 + ocw >= H) return -3;
+        if (piv_off[g + 1] - piv_off[g] < 1) return -3;
+    }
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic)
+    for (int32_t g = 0; g < N; g++)
+        match_point(i0, i1, H, W, xyuvav + 6 * (size_t)g, offset, piv_uv + 2 * piv_off[g],
+                    (int32_t)(piv_off[g + 1] - piv_off[g]), ocw, out + 3 * (size_t)g);
+    return 0;
+}
+
+/* =========================================================================================
+ * a8  neighbour offsets                                            MIMC_module.c:1266-1327
+ * ======================================================================================= */
+int32_t orc_get_ruv_neighbor(const double *xyuvav, int32_t N, int32_t dimx, int32_t dimy,
+                             float meter_per_spacing, float radius, int32_t *ruv, int32_t cap)
+{
+    (void)N;
+    int32_t cu = dimx / 2, cv = dimy / 2, nn = 0;
+    float cx = (float)xyuvav[6 * (size_t)cu + 0];
+    float cy = (float)xyuvav[6 * (size_t)cv * dimx + 1];
+    float lim = (radius * meter_per_spacing) * (radius * meter_per_spacing);
+    for (int32_t v = 0; v < dimy; v++)
+        for (int32_t u = 0; u < dimx; u++) {
+            float fx = (float)xyuvav[6 * (size_t)u + 0];               /* x taken from grid row 0 */
+            float fy = (float)xyuvav[6 * (size_t)v * dimx + 1];        /* y taken from grid column 0 */
+            float ddx = fx - cx, ddy = fy - cy;
+            float sq = ddx * ddx + ddy * ddy;
+            if (sq <= lim) {
+                if (nn < cap) { ruv[2 * nn] = u - cu; ruv[2 * nn + 1] = v - cv; }
+                nn++;
+            }
+        }
+    return nn <= cap ? nn : -1;
+}
+
+/* =========================================================================================
+ * a9-a10  QM pseudo-smoothing                                      MIMC_module.c:1986-2496
+ * ======================================================================================= */
+/* 6x6 Gauss-Jordan without pivoting, operation order as :2430-2496 */
+static void inv6(const double a[6][6], double I[6][6])
+{
+    double b[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { b[i][j] = a[i][j]; I[i][j] = (i == j) ? 1 : 0; }
+    for (int p = 0; p < 5; p++) {
+        double pivot = b[p][p];
+        for (int r = p + 1; r < 6; r++) {
+            double coeff = b[r][p] / pivot;
+            for (int c = 0; c < 6; c++) { b[r][c] -= b[p][c] * coeff; I[r][c] -= I[p][c] * coeff; }
+        }
+    }
+    for (int p = 5; p >= 0; p--) {
+        double pivot = b[p][p];
+        for (int r = p - 1; r >= 0; r--) {
+            double coeff = b[r][p] / pivot;
+            for (int c = 5; c >= 0; c--) { b[r][c] -= b[p][c] * coeff; I[r][c] -= I[p][c] * coeff; }
+        }
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) I[i][j] /= b[i][i];
+}
+
+/* weighted quadratic LSQ evaluated at (0,0), both outputs (:2314-2409) */
+static void quadfit_origin(const int32_t *xy, const double *z, const double *w, int n, double out[2])
+{
+    double Nm[6][6], IN[6][6];
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+            double acc = 0;
+            for (int o = 0; o < n; o++) {
+                double x = (double)xy[2 * o], y = (double)xy[2 * o + 1];
+                double A[6] = { x * x, x * y, y * y, x, y, 1 };
+                acc += A[r] * w[o] * A[c];
+            }
+            Nm[r][c] = acc;
+        }
+    inv6(Nm, IN);
+    for (int oc = 0; oc < 2; oc++) {
+        double atwb[6], coef[6];
+        for (int r = 0; r < 6; r++) {
+            double acc = 0;
+            for (int o = 0; o < n; o++) {
+                double x = (double)xy[2 * o], y = (double)xy[2 * o + 1];
+                double A[6] = { x * x, x * y, y * y, x, y, 1 };
+                acc += A[r] * w[o] * z[2 * o + oc];
+            }
+            atwb[r] = acc;
+        }
+        for (int r = 0; r < 6; r++) {
+            double acc = 0;
+            for (int c = 0; c < 6; c++) acc += IN[r][c] * atwb[c];
+            coef[r] = acc;
+        }
+        const double t[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 1 };  /* terms at xyi=(0,0): NaN/inf in any coef propagates */
+        double val = 0;
+        for (int c = 0; c < 6; c++) val += t[c] * coef[c];
+        out[oc] = val;
+    }
+}
+
+/* In place on dpf/dpf_dx/dpf_dy ([dimy][dimx]).  mvn: padded [N][Kmax][5]; nclus[N].
+ * max_sweeps: the reference's loop bound is NOI<=100, i.e. up to 101 sweeps (pass 101 to mirror).
+ * stats[0]=sweeps run (the reference's NOI at exit), stats[1]=points processed in total,
+ * stats[2]=points skipped by the T7 definition (NaN fit / no candidate). */
+int orc_qm_pseudosmooth(int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,
+                        const int32_t *ruv, int32_t nn, const float *mvn, int32_t Kmax,
+                        const int32_t *nclus, const double *xyuvav, int32_t max_sweeps, int64_t *stats)
+{
+    const int32_t N = dimx * dimy;
+    const double eig0 = 1500.0 / 300.0, eig1 = eig0 / 3.0;
+    uint8_t *mask0 = (uint8_t *)malloc(N), *mask = (uint8_t *)malloc(N), *next = (uint8_t *)malloc(N);
+    uint8_t **stack = (uint8_t **)calloc((size_t)max_sweeps + 2, sizeof(uint8_t *));
+    float *bx = (float *)malloc(sizeof(float) * N), *by = (float *)malloc(sizeof(float) * N);
+    int32_t *bid = (int32_t *)malloc(sizeof(int32_t) * N);
+    int32_t *nxy = (int32_t *)malloc(sizeof(int32_t) * 2 * nn);
+    double *nz = (double *)malloc(sizeof(double) * 2 * nn), *nw = (double *)malloc(sizeof(double) * nn);
+    const float nanv = sqrt(-1.0);
+    int64_t processed = 0, skipped = 0;
+    for (int32_t i = 0; i < N; i++) {                                   /* :2029-2055 */
+        int32_t id = dpf[i];
+        mask0[i] = (id >= 0 && !(mvn[((size_t)i * Kmax + id) * 5 + 4] >= 0.6)) ? 1 : 0;
+        bx[i] = nanv; by[i] = nanv; bid[i] = -1;
+    }
+    memcpy(mask, mask0, N);
+    stack[0] = (uint8_t *)malloc(N); memcpy(stack[0], mask0, N);
+    int32_t noi = 0, any = 1;
+    while (noi < max_sweeps && any) {
+        any = 0; noi++;
+        memset(next, 0, N);
+        for (int32_t v = 0; v < dimy; v++)
+            for (int32_t u = 0; u < dimx; u++) {
+                const int32_t idx = v * dimx + u;
+                if (!mask[idx]) continue;
+                int n = 0;
+                for (int32_t k = 0; k < nn; k++) {                      /* :2108-2126 */
+                    int32_t uu = u + ruv[2 * k], vv = v + ruv[2 * k + 1];
+                    if (uu < 0 || uu >= dimx || vv < 0 || vv >= dimy) continue;
+                    float fx = dpf_dx[vv * dimx + uu], fy = dpf_dy[vv * dimx + uu];
+                    if (isnan(fx) || isnan(fy)) continue;
+                    nxy[2 * n] = ruv[2 * k]; nxy[2 * n + 1] = ruv[2 * k + 1];
+                    nz[2 * n] = fx; nz[2 * n + 1] = fy;
+                    n++;
+                }
+                if (n < 10) continue;                                   /* :2131 */
+                processed++;
+                const double vx = xyuvav[6 * (size_t)idx + 4], vy = xyuvav[6 * (size_t)idx + 5];
+                const double den = (eig0 * eig1) * (vx * vx + vy * vy);
+                const double itm0 = (eig1 * vx * vx + eig0 * vy * vy) / den;      /* :2144-2146 */
+                const double itm1 = ((eig0 - eig1) * vx * vy) / den;
+                const double itm3 = (eig1 * vy * vy + eig0 * vx * vx) / den;
+                for (int o = 0; o < n; o++)                             /* :2151-2153 */
+                    nw[o] = exp(-(itm0 * nxy[2 * o] * nxy[2 * o] + 2 * itm1 * nxy[2 * o] * nxy[2 * o + 1] +
+                                  itm3 * nxy[2 * o + 1] * nxy[2 * o + 1]));
+                double fit[2];
+                quadfit_origin(nxy, nz, nw, n, fit);
+                const int32_t id = dpf[idx], nc = nclus[idx];
+                const float *cl = mvn + (size_t)idx * Kmax * 5;
+                double dmin = 1E+37; int32_t best = -1;
+                for (int32_t c = 0; c < nc; c++) {                      /* :2167-2180 */
+                    double cu_ = cl[5 * c], cv_ = cl[5 * c + 1];
+                    double sq = (fit[0] - cu_) * (fit[0] - cu_) + (fit[1] - cv_) * (fit[1] - cv_);
+                    if (sq < dmin) { dmin = sq; best = c; }
+                }
+                if (best < 0) { skipped++; continue; }                  /* T7 definition */
+                double gu = cl[5 * id], gv = cl[5 * id + 1], qu = cl[5 * best], qv = cl[5 * best + 1];
+                if ((gu - qu) * (gu - qu) + (gv - qv) * (gv - qv) < 0.0001) continue;   /* :2190 */
+                bx[idx] = (float)qu; by[idx] = (float)qv; bid[idx] = best;
+                any = 1;
+                for (int o = 0; o < n; o++) {                           /* :2203-2210 */
+                    int32_t j = (v + nxy[2 * o + 1]) * dimx + (u + nxy[2 * o]);
+                    if (mask0[j]) next[j] = 1;
+                }
+            }
+        for (int32_t i = 0; i < N; i++)                                 /* Jacobi commit :2218-2233 */
+            if (bid[i] >= 0) {
+                dpf_dx[i] = bx[i]; dpf_dy[i] = by[i]; dpf[i] = bid[i];
+                bx[i] = nanv; by[i] = nanv; bid[i] = -1;
+            }
+        int fluct = 0;                                                  /* :2237-2268 */
+        for (int32_t s = noi - 1; s >= 0 && !fluct; s--)
+            if (memcmp(stack[s], next, N) == 0) fluct = 1;
+        if (fluct) { noi--; break; }
+        stack[noi] = (uint8_t *)malloc(N); memcpy(stack[noi], next, N);
+        memcpy(mask, next, N);
+    }
+    if (stats) { stats[0] = noi; stats[1] = processed; stats[2] = skipped; }
+    for (int32_t s = 0; s <= max_sweeps + 1; s++) free(stack[s]);
+    free(stack); free(mask0); free(mask); free(next); free(bx); free(by); free(bid);
+    free(nxy); free(nz); free(nw);
+    return 0;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,237 @@
+/*
+ * oracle/ref_harness.c -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+ *
+ * Thin flat-pointer harness around the UNMODIFIED reference sources.  It is compiled together
+ * with /root/reference/MIMC_module.c and /root/reference/GMA.c *where they lie* (see
+ * oracle/Makefile target `ref`), producing oracle/_ref/libmimc3_ref.so.  Nothing from the
+ * reference is copied into this repository: this file only declares the process globals the
+ * reference expects from its main() (MIMC_main.c:38-42) and marshals flat arrays into the
+ * reference's GMA structs (GMA.h:68-91) before calling the reference's own functions.
+ *
+ * Used for: (1) pinning oracle/mimc3_oracle.c (the CPU restatement) bit-for-bit,
+ *           (2) generating tests/golden/ vectors (tests/golden/make_golden.py),
+ *           (3) bench.py's cpu_baseline leg (kind "reference").
+ *
+ * T4: the reference reads the never-written last row/column of `sarea`.
+ * The library is linked with -Wl,--wrap=malloc and __wrap_malloc below zero-fills, so those
+ * cells are 0.0 deterministically.  This is the definition the restatement and HIP path follow.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <omp.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include "MIMC_module.h"
+
+/* ---- process globals the reference module declares extern (MIMC_module.c:28-32) ---- */
+float dt;
+int32_t num_dp;
+int32_t num_grid, dimx_vmap, dimy_vmap;
+param param_mimc2;
+GMA_float **kernel;
+
+/* zero-filling allocator for every malloc inside the reference objects (T4) */
+void *__wrap_malloc(size_t n) { return calloc(1, n ? n : 1); }
+
+/* ---- helpers: wrap caller memory in GMA structs without copying the payload ---- */
+static GMA_float *wrap_float(const float *p, int32_t nr, int32_t nc)
+{
+    GMA_float *g = (GMA_float *)calloc(1, sizeof(GMA_float));
+    g->nrows = nr; g->ncols = nc; g->data = (float *)p;
+    g->val = (float **)calloc((size_t)(nr > 0 ? nr : 1), sizeof(float *));
+    for (int32_t r = 0; r < nr; r++) g->val[r] = g->data + (size_t)r * nc;
+    return g;
+}
+static GMA_double *wrap_double(const double *p, int32_t nr, int32_t nc)
+{
+    GMA_double *g = (GMA_double *)calloc(1, sizeof(GMA_double));
+    g->nrows = nr; g->ncols = nc; g->data = (double *)p;
+    g->val = (double **)calloc((size_t)(nr > 0 ? nr : 1), sizeof(double *));
+    for (int32_t r = 0; r < nr; r++) g->val[r] = g->data + (size_t)r * nc;
+    return g;
+}
+static GMA_int32 *wrap_int32(const int32_t *p, int32_t nr, int32_t nc)
+{
+    GMA_int32 *g = (GMA_int32 *)calloc(1, sizeof(GMA_int32));
+    g->nrows = nr; g->ncols = nc; g->data = (int32_t *)p;
+    g->val = (int32_t **)calloc((size_t)(nr > 0 ? nr : 1), sizeof(int32_t *));
+    for (int32_t r = 0; r < nr; r++) g->val[r] = g->data + (size_t)r * nc;
+    return g;
+}
+#define UNWRAP(g) do { free((g)->val); free(g); } while (0)
+
+/* the reference prints progress with printf; silence fd 1 around calls unless MIMC3_REF_VERBOSE is set */
+static void quiet_begin(int *saved)
+{
+    *saved = -1;
+    if (getenv("MIMC3_REF_VERBOSE")) return;
+    fflush(stdout);
+    *saved = dup(1);
+    int nul = open("/dev/null", O_WRONLY);
+    if (nul >= 0) { dup2(nul, 1); close(nul); }
+}
+static void quiet_end(int saved)
+{
+    fflush(stdout);
+    if (saved >= 0) { dup2(saved, 1); close(saved); }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * get_uv_pivot (MIMC_module.c:543-602) -> CSR.  Returns total pivot count, or -1 when `cap`
+ * (pairs) is too small, or -2 when a point has zero pivots (reference overflows there, T5).
+ * ---------------------------------------------------------------------------------------- */
+int64_t ref_get_uv_pivot(const double *xyuvav, int32_t N, float dt_, float mpp, float aw_sf,
+                         float aw_cre, int32_t ocw, int32_t H, int32_t W,
+                         int64_t *piv_off, int32_t *piv_uv, int64_t cap)
+{
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_float img; memset(&img, 0, sizeof img); img.nrows = H; img.ncols = W;
+    param p; memset(&p, 0, sizeof p); p.mpp = mpp; p.AW_SF = aw_sf; p.AW_CRE = aw_cre;
+    int sv; quiet_begin(&sv);
+    GMA_int32 **pv = get_uv_pivot(xy, dt_, p, ocw, &img);
+    quiet_end(sv);
+    int64_t tot = 0, rc = 0;
+    piv_off[0] = 0;
+    for (int32_t g = 0; g < N; g++) {
+        int32_t n = pv[g]->nrows;
+        if (n <= 0) rc = -2;
+        if (rc == 0 && tot + n > cap) rc = -1;
+        if (rc == 0)
+            for (int32_t k = 0; k < n; k++) {
+                piv_uv[2 * (tot + k) + 0] = pv[g]->val[k][0];
+                piv_uv[2 * (tot + k) + 1] = pv[g]->val[k][1];
+            }
+        tot += n > 0 ? n : 0;
+        piv_off[g + 1] = tot;
+        if (n > 0) GMA_int32_destroy(pv[g]);
+    }
+    free(pv);
+    UNWRAP(xy);
+    return rc < 0 ? rc : tot;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * matching_ncc_dlc_2 (MIMC_module.c:805-842).  `nthreads` <= 0 keeps the OpenMP default.
+ * ---------------------------------------------------------------------------------------- */
+int ref_matching_ncc_dlc_2(const float *i0, const float *i1, int32_t H, int32_t W,
+                           const double *xyuvav, int32_t N, const int32_t *offset,
+                           const int32_t *piv_uv, const int64_t *piv_off, int32_t ocw,
+                           float *out, int32_t nthreads)
+{
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    GMA_float *g0 = wrap_float(i0, H, W), *g1 = wrap_float(i1, H, W);
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_int32 **pv = (GMA_int32 **)calloc((size_t)N, sizeof(GMA_int32 *));
+    for (int32_t g = 0; g < N; g++)
+        pv[g] = wrap_int32(piv_uv + 2 * piv_off[g], (int32_t)(piv_off[g + 1] - piv_off[g]), 2);
+    int32_t off[2] = { offset[0], offset[1] };
+    GMA_float *res = matching_ncc_dlc_2(g0, g1, xy, off, pv, ocw, 10.0f, 1.8f);
+    memcpy(out, res->data, sizeof(float) * 3 * (size_t)N);
+    GMA_float_destroy(res);
+    for (int32_t g = 0; g < N; g++) UNWRAP(pv[g]);
+    free(pv);
+    UNWRAP(xy); UNWRAP(g0); UNWRAP(g1);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * get_ruv_neighbor (MIMC_module.c:1266-1327).  Returns the neighbour count (or -1: cap).
+ * ---------------------------------------------------------------------------------------- */
+int32_t ref_get_ruv_neighbor(const double *xyuvav, int32_t N, int32_t dimx, int32_t dimy,
+                             float meter_per_spacing, float radius, int32_t *ruv, int32_t cap)
+{
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    num_grid = N; dimx_vmap = dimx; dimy_vmap = dimy;
+    param_mimc2.meter_per_spacing = meter_per_spacing;
+    GMA_int32 *r = get_ruv_neighbor(xy, radius);
+    int32_t nn = r->nrows;
+    if (nn <= cap) memcpy(ruv, r->data, sizeof(int32_t) * 2 * (size_t)nn);
+    GMA_int32_destroy(r);
+    UNWRAP(xy);
+    return nn <= cap ? nn : -1;
+}
+
+/* ragged mvn_dp <-> padded [N][Kmax][5] */
+static GMA_float **mvn_from_padded(const float *mvn, const int32_t *nclus, int32_t N, int32_t Kmax)
+{
+    GMA_float **m = (GMA_float **)calloc((size_t)N, sizeof(GMA_float *));
+    for (int32_t g = 0; g < N; g++) {
+        m[g] = GMA_float_create(nclus[g], 5);
+        memcpy(m[g]->data, mvn + (size_t)g * Kmax * 5, sizeof(float) * 5 * (size_t)nclus[g]);
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Post-processing chain up to the QM input: calc_mean_var_num_dp_cluster -> get_dpf0 ->
+ * get_ruv_neighbor(radius_dpf1) -> get_dpf1 (MIMC_module.c:905-927).  Produces the padded
+ * candidate tensor and the initial dpf/dpf_dx/dpf_dy that get_dpf_pseudosmoothing consumes.
+ * Returns max cluster count seen (or -1 if it exceeds Kmax).
+ * ---------------------------------------------------------------------------------------- */
+int32_t ref_postprocess_prep(const float *dp, int32_t ndp, const double *xyuvav, int32_t N,
+                             int32_t dimx, int32_t dimy, float dt_, float mpp,
+                             float meter_per_spacing, float radius_dpf1, int32_t Kmax,
+                             float *mvn, int32_t *nclus, int32_t *dpf, float *dpf_dx, float *dpf_dy)
+{
+    int sv; quiet_begin(&sv);
+    dt = dt_; num_dp = ndp; num_grid = N; dimx_vmap = dimx; dimy_vmap = dimy;
+    param_mimc2.mpp = mpp; param_mimc2.meter_per_spacing = meter_per_spacing;
+    param_mimc2.radius_neighbor_dpf1 = radius_dpf1;
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_float **dps = (GMA_float **)calloc((size_t)ndp, sizeof(GMA_float *));
+    for (int32_t k = 0; k < ndp; k++) dps[k] = wrap_float(dp + (size_t)k * N * 3, N, 3);
+    GMA_float **m = calc_mean_var_num_dp_cluster(dps, ndp);
+    int32_t kmax = 0;
+    for (int32_t g = 0; g < N; g++) if (m[g]->nrows > kmax) kmax = m[g]->nrows;
+    int32_t rc = kmax;
+    if (kmax > Kmax) rc = -1;
+    else {
+        GMA_int32 *d0 = get_dpf0(m, 0.6f);
+        GMA_int32 *ruv = get_ruv_neighbor(xy, radius_dpf1);
+        GMA_float *dx = GMA_float_create(dimy, dimx), *dy = GMA_float_create(dimy, dimx);
+        get_dpf1(d0, dx, dy, ruv, m, xy);
+        memset(mvn, 0, sizeof(float) * 5 * (size_t)N * Kmax);
+        for (int32_t g = 0; g < N; g++) {
+            nclus[g] = m[g]->nrows;
+            memcpy(mvn + (size_t)g * Kmax * 5, m[g]->data, sizeof(float) * 5 * (size_t)m[g]->nrows);
+        }
+        memcpy(dpf, d0->data, sizeof(int32_t) * (size_t)N);
+        memcpy(dpf_dx, dx->data, sizeof(float) * (size_t)N);
+        memcpy(dpf_dy, dy->data, sizeof(float) * (size_t)N);
+        GMA_int32_destroy(d0); GMA_int32_destroy(ruv); GMA_float_destroy(dx); GMA_float_destroy(dy);
+    }
+    for (int32_t g = 0; g < N; g++) GMA_float_destroy(m[g]);
+    free(m);
+    for (int32_t k = 0; k < ndp; k++) UNWRAP(dps[k]);
+    free(dps);
+    UNWRAP(xy);
+    quiet_end(sv);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * get_dpf_pseudosmoothing (MIMC_module.c:1986-2312): in place on dpf, dpf_dx, dpf_dy.
+ * ---------------------------------------------------------------------------------------- */
+int ref_get_dpf_pseudosmoothing(int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx,
+                                float *dpf_dy, const int32_t *ruv, int32_t nn, const float *mvn,
+                                int32_t Kmax, const int32_t *nclus, const double *xyuvav)
+{
+    int32_t N = dimx * dimy;
+    num_grid = N; dimx_vmap = dimx; dimy_vmap = dimy;
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_int32 *gd = wrap_int32(dpf, dimy, dimx);
+    GMA_float *gx = wrap_float(dpf_dx, dimy, dimx), *gy = wrap_float(dpf_dy, dimy, dimx);
+    GMA_int32 *gr = wrap_int32(ruv, nn, 2);
+    GMA_float **m = mvn_from_padded(mvn, nclus, N, Kmax);
+    int sv; quiet_begin(&sv);
+    get_dpf_pseudosmoothing(gd, gx, gy, gr, m, xy);
+    quiet_end(sv);
+    for (int32_t g = 0; g < N; g++) GMA_float_destroy(m[g]);
+    free(m);
+    UNWRAP(gr); UNWRAP(gx); UNWRAP(gy); UNWRAP(gd); UNWRAP(xy);
+    return 0;
+}
+
+int ref_num_threads(void) { return omp_get_max_threads(); }

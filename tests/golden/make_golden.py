@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libmimc3_ref.so).
+
+Run in the build container only (it needs /root/reference to have been compiled by
+`make -C oracle ref`):   python tests/golden/make_golden.py
+
+Each fixture is data only: seeded synthetic inputs (stored as uint8/uint16 DN to stay small) and
+the reference's outputs for them (pivots, out[N,3]; QM planes before/after).  The reference's
+matcher output is deterministic; the harness zero-fills malloc (T4).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from mimc3_amd import synth  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# name -> make_small kwargs (+ optional post-edit hook)
+MATCH_CASES = {
+    # integer shift on the corridor, |cos|>|sin| branch, quadrant (+u, -v)
+    "int_shift_q1": dict(seed=101, shift=(3, -2), angle_deg=30.0, ocw=7, speed=1200.0),
+    # |sin|>|cos| branch, quadrant (-u, +v), sub-pixel bilinear shift, DN noise
+    "subpix_q3": dict(seed=102, shift=(-2, 3), angle_deg=-120.0, ocw=10, speed=1500.0,
+                      subpixel=(0.35, 0.6), noise_dn=2),
+    # quadrant (+u, +v) (south-going: pivots (k, k-1) quirk T5), null blobs -> exclusion + some -3
+    "nulls_q4": dict(seed=103, shift=(2, 2), angle_deg=-45.0, ocw=8, speed=1300.0, null_frac=0.12),
+    # quadrant (-u, -v), shift 2 px OFF the corridor (T3: -2.0 cells enter the fit)
+    "offcorridor_q2": dict(seed=104, shift=(-4, -1), angle_deg=135.0, ocw=7, speed=1400.0),
+    # 16-bit DN (f32 products round, T1), non-zero CP offset applied to the window only (T6)
+    "u16_offset": dict(seed=105, shift=(5, -3), angle_deg=20.0, ocw=9, speed=1600.0, bits=16, offset=(2, -1)),
+    # grid so close to the border that windows hang over the image edge (zero fill, :877-884)
+    "edge_windows": dict(seed=106, shift=(1, -1), angle_deg=60.0, ocw=7, speed=900.0, margin=10,
+                         h=120, w=128, dimx=10, dimy=9),
+}
+
+
+def edit_case(name, c):
+    if name == "nulls_q4":
+        # a fully null block: chips inside it are >80 % null -> (NaN, NaN, -3)
+        c.i0[20:70, 20:80] = 0.0
+        c.i1[90:140, 100:170] = 0.0
+    return c
+
+
+def main():
+    ref = Oracle("reference")
+    for name, kw in MATCH_CASES.items():
+        c = edit_case(name, synth.make_small(**kw))
+        H, W = c.i0.shape
+        off, uv = ref.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+        out = ref.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+        # swapped pass exactly as the CLI does it (MIMC_main.c:272-293): images exchanged,
+        # offset negated, pivots negated; (du,dv) negation is the caller's business
+        out_sw = ref.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw)
+        bits = kw.get("bits", 8)
+        dn = np.uint8 if bits == 8 else np.uint16
+        assert np.array_equal(c.i0, c.i0.astype(dn).astype(np.float32))
+        np.savez_compressed(
+            os.path.join(OUT, f"match_{name}.npz"),
+            i0=c.i0.astype(dn), i1=c.i1.astype(dn), xyuvav=c.xyuvav, offset=c.offset,
+            ocw=np.int32(c.ocw), dt=np.float32(c.dt), mpp=np.float32(c.mpp),
+            piv_off=off, piv_uv=uv, out=out, out_swapped=out_sw)
+        inv = int((out[:, 2] == -3).sum())
+        print(f"match_{name}: N={c.n} npiv={int(off[-1])} invalid={inv} "
+              f"median=({np.nanmedian(out[:, 0]):.3f},{np.nanmedian(out[:, 1]):.3f}) shift={c.shift}")
+
+    # QM: candidates -> (reference clustering, dpf0, dpf1) -> pseudo-smoothing before/after
+    for name, (dimx, dimy, seed, ang) in {"qm_40x40": (40, 40, 5, 37.0), "qm_57x33": (57, 33, 8, -70.0)}.items():
+        xy = synth.make_grid(dimx, dimy, 60, 60, 20, 20, 1806.0, angle_deg=ang)
+        mps = float(np.float32(xy[1, 0] - xy[0, 0]))
+        dp = synth.synth_candidates(dimx, dimy, seed=seed)
+        mvn, nclus, dpf, dx, dy = ref.postprocess_prep(dp, xy, dimx, dimy, 16.0, 15.0, mps)
+        ruv = ref.get_ruv_neighbor(xy, dimx, dimy, mps, 5.0)
+        d2, x2, y2, _ = ref.qm(dpf, dx, dy, ruv, mvn, nclus, xy)
+        kmax = int(nclus.max())
+        np.savez_compressed(
+            os.path.join(OUT, f"{name}.npz"),
+            xyuvav=xy, meter_per_spacing=np.float32(mps), radius=np.float32(5.0), ruv=ruv,
+            mvn=mvn[:, :kmax].copy(), nclus=nclus, dpf_in=dpf, dx_in=dx, dy_in=dy,
+            dpf_out=d2, dx_out=x2, dy_out=y2)
+        print(f"{name}: nn={ruv.shape[0]} kmax={kmax} changed={(d2 != dpf).sum()}")
+
+
+if __name__ == "__main__":
+    main()

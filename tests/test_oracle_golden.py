@@ -1,0 +1,32 @@
+"""CPU: the restatement (oracle/mimc3_oracle.c) reproduces the reference-generated golden vectors
+bit-for-bit -- this is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, golden_files, load_match_golden
+
+
+@pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
+def test_match_golden(oracle, path):
+    g = load_match_golden(path)
+    H, W = g["i0"].shape
+    off, uv = oracle.get_uv_pivot(g["xyuvav"], g["dt"], g["mpp"], g["ocw"], H, W)
+    assert np.array_equal(off, g["piv_off"]) and np.array_equal(uv, g["piv_uv"])
+    out = oracle.match(g["i0"], g["i1"], g["xyuvav"], g["offset"], off, uv, g["ocw"])
+    assert_bits_equal(out, g["out"], "forward")
+    out_sw = oracle.match(g["i1"], g["i0"], g["xyuvav"], -g["offset"], off, -uv, g["ocw"])
+    assert_bits_equal(out_sw, g["out_swapped"], "swapped")
+
+
+@pytest.mark.parametrize("path", golden_files("qm_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_qm_golden(oracle, path):
+    z = np.load(path)
+    dimy, dimx = z["dpf_in"].shape
+    ruv = oracle.get_ruv_neighbor(z["xyuvav"], dimx, dimy, float(z["meter_per_spacing"]), float(z["radius"]))
+    assert np.array_equal(ruv, z["ruv"])
+    d, x, y, stats = oracle.qm(z["dpf_in"], z["dx_in"], z["dy_in"], ruv, z["mvn"], z["nclus"], z["xyuvav"])
+    assert stats[2] == 0, "fixture must not hit the T7 (NaN-fit) definition"
+    assert np.array_equal(d, z["dpf_out"])
+    assert_bits_equal(x, z["dx_out"], "dx")
+    assert_bits_equal(y, z["dy_out"], "dy")
+    assert (d != z["dpf_in"]).sum() > 0

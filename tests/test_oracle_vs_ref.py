@@ -1,0 +1,56 @@
+"""CPU, build container only: restatement == compiled reference on fresh seeded inputs
+(skipped on the GPU box unless oracle/_ref travelled there prebuilt -- it does, and then it runs)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from mimc3_amd import synth
+
+CASES = [
+    dict(seed=21, shift=(3, -2), angle_deg=10.0, ocw=7),
+    dict(seed=22, shift=(-3, 1), angle_deg=170.0, ocw=12, noise_dn=3, null_frac=0.08),
+    dict(seed=23, shift=(0, 4), angle_deg=-88.0, ocw=9, subpixel=(0.5, 0.25), bits=16),
+    dict(seed=24, shift=(2, 2), angle_deg=-40.0, ocw=15, speed=2500.0, h=220, w=230, offset=(-1, 2)),
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: f"seed{k['seed']}")
+def test_match_vs_reference(oracle, reference, kw):
+    c = synth.make_small(**kw)
+    H, W = c.i0.shape
+    o1, u1 = reference.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    o2, u2 = oracle.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    assert np.array_equal(o1, o2) and np.array_equal(u1, u2)
+    assert_bits_equal(oracle.match(c.i0, c.i1, c.xyuvav, c.offset, o1, u1, c.ocw),
+                      reference.match(c.i0, c.i1, c.xyuvav, c.offset, o1, u1, c.ocw))
+
+
+def test_pivot_all_directions(oracle, reference):
+    """every 7.5 degrees, slow and fast: both normalisation branches, all sign quadrants (T5)"""
+    n = 96
+    ang = np.deg2rad(np.arange(n) * 7.5 - 180.0)
+    spd = np.where(np.arange(n) % 2 == 0, 300.0, 4000.0)
+    xy = np.zeros((n, 6))
+    xy[:, 2] = 400 + np.arange(n) % 7; xy[:, 3] = 380 + np.arange(n) % 5
+    xy[:, 0] = xy[:, 2] * 15; xy[:, 1] = -xy[:, 3] * 15
+    xy[:, 4] = spd * np.cos(ang); xy[:, 5] = spd * np.sin(ang)
+    for ocw in (7, 15, 30, 40):
+        a = reference.get_uv_pivot(xy, 16.0, 15.0, ocw, 800, 830)
+        b = oracle.get_uv_pivot(xy, 16.0, 15.0, ocw, 800, 830)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dims", [(40, 40, 5, 37.0), (61, 47, 9, -100.0)])
+def test_qm_vs_reference(oracle, reference, dims):
+    dimx, dimy, seed, ang = dims
+    xy = synth.make_grid(dimx, dimy, 60, 60, 20, 20, 1806.0, angle_deg=ang)
+    mps = float(np.float32(xy[1, 0] - xy[0, 0]))
+    dp = synth.synth_candidates(dimx, dimy, seed=seed)
+    mvn, nclus, dpf, dx, dy = reference.postprocess_prep(dp, xy, dimx, dimy, 16.0, 15.0, mps)
+    ruv = reference.get_ruv_neighbor(xy, dimx, dimy, mps, 5.0)
+    assert np.array_equal(ruv, oracle.get_ruv_neighbor(xy, dimx, dimy, mps, 5.0))
+    a = reference.qm(dpf, dx, dy, ruv, mvn, nclus, xy)
+    b = oracle.qm(dpf, dx, dy, ruv, mvn, nclus, xy)
+    assert b[3][2] == 0
+    assert np.array_equal(a[0], b[0])
+    assert_bits_equal(a[1], b[1]); assert_bits_equal(a[2], b[2])
