@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: grid-points/s of the DLC/NCC matcher.
+
+    python bench.py --gpus N --steps K --warmup W           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one matcher pass (matching_ncc_dlc_2) over one batch of synthetic grid points.
+Workload at N=1 = BASELINE configs[1]: 4096x4096 synthetic pair, 200,000 grid points (500x400),
+ocw 16 (33x33 chip), ~15 DLC pivots (65x65 window).  Inputs (both images, xyuvav, pivot CSR) are
+resident in HBM before the timed region.  At N>1 every rank matches its own 200,000-point lattice
+on the replicated pair (lattice r is shifted r px in x: together an N-times denser grid; weak
+scaling), then the (u,v,ncc) field is re-assembled on every GPU with one RCCL all-gather.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1,
+`cpu_baseline` (the compiled reference OpenMP path when oracle/_ref travelled here, else the
+parity-verified C restatement) and a parity figure against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def algorithmic_bytes(piv_off, piv_uv, ocw):
+    """B = 4(2ocw+1)^2 + 4*Dy2*Dx2 + 48 + 8*npiv + 12 per grid point, summed."""
+    npiv = (piv_off[1:] - piv_off[:-1]).astype(np.int64)
+    last = piv_uv[piv_off[1:] - 1].astype(np.int64)
+    dx2 = np.abs(last[:, 0]) + ocw + 2
+    dy2 = np.abs(last[:, 1]) + ocw + 2
+    chip = 4 * (2 * ocw + 1) ** 2
+    return int((chip + 4 * (2 * dx2 + 1) * (2 * dy2 + 1) + 48 + 8 * npiv + 12).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    from mimc3_amd import api, synth   # raises if libmimc3_hip.so is missing: no CPU fallback
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- inputs (seeded; identical images on every rank) -------------------------------------
+    case = synth.make_case(args.config)
+    H, W = case.i0.shape
+    xy = case.xyuvav.copy()
+    if rank:                                   # rank r's lattice: shifted r px in x
+        xy[:, 2] += rank
+        xy[:, 0] += rank * case.mpp
+    n = xy.shape[0]
+    piv_off, piv_uv = api.get_uv_pivot(xy, case.dt, case.mpp, case.ocw, H, W)
+    extent = api.pivot_extent(piv_off, piv_uv)
+    alg_bytes = algorithmic_bytes(piv_off, piv_uv, case.ocw)
+
+    t_h2d0 = time.perf_counter()
+    d_i0 = torch.from_numpy(case.i0).to(dev)
+    d_i1 = torch.from_numpy(case.i1).to(dev)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t_h2d0
+    d_xy = torch.from_numpy(xy).to(dev)
+    d_uv = torch.from_numpy(piv_uv).to(dev)
+    d_off = torch.from_numpy(piv_off).to(dev)
+    d_out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_all = torch.empty((world * n, 3), dtype=torch.float32, device=dev) if world > 1 else None
+
+    ctx = api.Context(local_rank)
+    ctx.set_images_dev(d_i0.data_ptr(), d_i1.data_ptr(), H, W, keep=(d_i0, d_i1))
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        ctx.matching_ncc_dlc_2_dev(d_xy.data_ptr(), n, case.offset, d_uv.data_ptr(), d_off.data_ptr(), extent,
+                                   case.ocw, d_out.data_ptr(), stream=stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        total_pts = world * n * args.steps
+        value = total_pts / elapsed
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "grid-points/s (DLC NCC match)", "value": value, "unit": "grid-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 pixels, f64 accumulate", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points per GPU "
+                                   f"({case.dimx}x{case.dimy}), ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), "
+                                   f"{extent[0]} pivots max, window up to {2 * (extent[1] + case.ocw + 2) + 1}^2",
+                       "grid_points_per_gpu": n, "image": [H, W], "ocw": case.ocw,
+                       "parallelism": f"grid-point shard x{world}" + (", RCCL all-gather of [N,3]" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "match_ncc_dlc_f32", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "h2d_images_s": t_h2d,
+        }
+        got = d_out.cpu().numpy()
+        valid = got[:, 2] > -2.5
+        res["check"] = {"valid_frac": float(valid.mean()),
+                        "median_du_dv": [float(np.nanmedian(got[:, 0])), float(np.nanmedian(got[:, 1]))],
+                        "true_shift": list(case.shift)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"], res["parity"] = cpu_baseline(case, xy, piv_off, piv_uv, got, args.cpu_sample)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(case, xy, piv_off, piv_uv, gpu_out, sample):
+    """Time the CPU path on this box's host cores on a bounded sample of the SAME workload, and
+    use its output as the parity checker for the GPU result (the oracle is only the checker)."""
+    from oracle import oracle as orc
+    kind = "reference" if orc.available("reference") else "port"
+    if kind == "port" and not orc.available("port"):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    o = orc.Oracle(kind)
+    n = xy.shape[0]
+    cores = o.num_threads()
+    if sample <= 0:
+        # aim at ~15 s of CPU work: calibrate on 2,000 points
+        idx = np.arange(0, n, max(1, n // 2000))[:2000]
+        t0 = time.perf_counter()
+        _subset_match(o, case, xy, piv_off, piv_uv, idx)
+        rate = len(idx) / (time.perf_counter() - t0)
+        sample = int(min(n, max(2000, rate * 15.0)))
+    idx = np.unique(np.linspace(0, n - 1, sample).astype(np.int64))
+    t0 = time.perf_counter()
+    cpu = _subset_match(o, case, xy, piv_off, piv_uv, idx)
+    dt = time.perf_counter() - t0
+    g = gpu_out[idx]
+    nan_same = bool(np.array_equal(np.isnan(g), np.isnan(cpu)))
+    diff = float(np.nanmax(np.abs(g - cpu))) if np.isfinite(cpu).any() else 0.0
+    bits = bool(nan_same and np.array_equal(np.nan_to_num(g).view(np.uint32), np.nan_to_num(cpu).view(np.uint32)))
+    base = {"value": len(idx) / dt, "unit": "grid-points/s", "cores": cores, "kind": kind,
+            "sample": f"{len(idx)} of {n} grid points (evenly spaced), one matcher pass, {dt:.1f} s, OpenMP dynamic"}
+    par = {"points": int(len(idx)), "invalid_mask_equal": nan_same, "max_abs_diff_px": diff, "bit_identical": bits}
+    return base, par
+
+
+def _subset_match(o, case, xy, piv_off, piv_uv, idx):
+    cnt = (piv_off[idx + 1] - piv_off[idx]).astype(np.int64)
+    off = np.zeros(len(idx) + 1, np.int64)
+    np.cumsum(cnt, out=off[1:])
+    sel = np.concatenate([np.arange(piv_off[i], piv_off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, np.int64)
+    return o.match(case.i0, case.i1, xy[idx], case.offset, off, piv_uv[sel], case.ocw)
+
+
+if __name__ == "__main__":
+    main()

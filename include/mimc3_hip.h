@@ -1,0 +1,111 @@
+/*
+ * mimc3_hip.h -- C ABI of libmimc3_hip.so: the MI355X (gfx950) implementation of MIMC3's
+ * per-grid-point DLC/NCC matching loop and QM pseudo-smoothing update.
+ *
+ * The reference has no plugin/FFI layer; its seam for this path is three plain C functions
+ * (MIMC_module.h:41,46,58).  Each entry point below names the reference interface it replaces.
+ * Plain pointers and sizes only; no GMA structs here (see mimc3_gma_shim.h for the struct-level
+ * drop-in with the reference's exact signatures), no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MIMC3_E* code, or a positive hipError_t;
+ *     mimc3_last_error() returns a thread-local message for the last failure.
+ *   - images are row-major float32 [H][W] as produced by GMA_float_load_tiff (GMA.c:246-316).
+ *   - xyuvav is row-major float64 [N][6] = map x, map y, image u, image v, a-priori vx, vy.
+ *   - DLC pivots are CSR: piv_off int64 [N+1], piv_uv int32 [P][2] (u, v offsets), which is the
+ *     flattening of the reference's ragged `GMA_int32 **uv_pivot`.
+ *   - "_dev" functions take DEVICE pointers and enqueue on the given hipStream_t (passed as
+ *     void*; NULL = the default stream) without synchronising; the others take HOST pointers,
+ *     copy, run, and synchronise (drop-in semantics).
+ *   - there is NO CPU fallback anywhere in this library.
+ */
+#ifndef MIMC3_HIP_H
+#define MIMC3_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMC3_EINVAL   (-1)  /* bad argument (null pointer, non-positive size, ocw < 2 ...)      */
+#define MIMC3_EBOUNDS  (-2)  /* a chip would leave the image, or a point has zero pivots: the
+                                reference reads/writes out of bounds there (MIMC_module.c:852,
+                                :589-591); this library refuses instead                        */
+#define MIMC3_ECAP     (-3)  /* caller-provided output capacity too small                        */
+#define MIMC3_ENODEV   (-4)  /* no usable HIP device                                             */
+#define MIMC3_ESTATE   (-5)  /* context in the wrong state (e.g. images not set)                 */
+
+typedef struct mimc3_ctx mimc3_ctx;   /* opaque: device id, stream, resident images, workspaces */
+
+/* ---- context: keeps both images resident in HBM across the CLI's 32 matcher passes
+ *      (MIMC_main.c:261-350 calls the matcher 32x on 4 image pairs) ------------------------- */
+int  mimc3_ctx_create(int device, mimc3_ctx **out);
+void mimc3_ctx_destroy(mimc3_ctx *ctx);
+const char *mimc3_last_error(void);
+
+/* Upload a host image pair (replaces the reference holding GMA_float *i0,*i1 in host RAM). */
+int mimc3_ctx_set_images(mimc3_ctx *ctx, const float *i0, const float *i1, int32_t H, int32_t W);
+/* Adopt device-resident images (no copy; caller keeps ownership, must outlive the context use). */
+int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i1, int32_t H, int32_t W);
+
+/* ---- a2: DLC pivot generator.  Replaces get_uv_pivot (MIMC_module.h:41, MIMC_module.c:543-602).
+ *      Host code (libm-exact float/double mix of the reference).  Two-call protocol: pass
+ *      piv_uv=NULL to get the total pivot count in *total and piv_off filled; then call again
+ *      with capacity `cap` (pairs).  MIMC3_EBOUNDS if any point gets zero pivots. ------------- */
+int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre,
+                       int32_t ocw, int32_t H, int32_t W,
+                       int64_t *piv_off /*[N+1]*/, int32_t *piv_uv /*[cap][2] or NULL*/, int64_t cap,
+                       int64_t *total);
+
+/* ---- a3-a7: matcher.  Replaces matching_ncc_dlc_2 (MIMC_module.h:46, MIMC_module.c:805-842)
+ *      including extract_refchip/extract_sarea/investigate_valid_grid/find_ncc_peak.
+ *      out [N][3] = (du, dv, ncc_peak); invalid point = (NaN, NaN, -3)   (MIMC_module.c:685-687).
+ *      `swap` != 0 matches i1 -> i0 (the CLI's "swapped forward" pass, MIMC_main.c:284): the
+ *      caller still negates offset, pivots and the resulting (du,dv) exactly as main() does. --- */
+int mimc3_match_ncc_dlc(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const int32_t offset[2],
+                        const int32_t *piv_uv, const int64_t *piv_off, int32_t ocw, int32_t swap,
+                        float *out /*[N][3] host*/);
+
+/* Device-resident variant used by bench.py and the multi-GPU shard path: all pointers are device
+ * pointers; `max_abs_piv_u/v` = max over points of |last pivot| per axis (sizes the LDS window;
+ * mimc3_pivot_extent() computes it from a host CSR).  Enqueues on `stream`, no sync. */
+int mimc3_match_ncc_dlc_dev(mimc3_ctx *ctx, const double *d_xyuvav, int32_t N, int32_t off_u, int32_t off_v,
+                            const int32_t *d_piv_uv, const int64_t *d_piv_off, int32_t max_npiv,
+                            int32_t max_abs_piv_u, int32_t max_abs_piv_v, int32_t ocw, int32_t swap,
+                            float *d_out, void *stream);
+int mimc3_pivot_extent(const int32_t *piv_uv, const int64_t *piv_off, int32_t N,
+                       int32_t *max_npiv, int32_t *max_abs_u, int32_t *max_abs_v);
+
+/* ---- a8: neighbour offsets.  Replaces get_ruv_neighbor (MIMC_module.h:56, :1266-1327).
+ *      Host code.  Returns the count in *nn; MIMC3_ECAP if it exceeds cap (pairs). ------------- */
+int mimc3_get_ruv_neighbor(const double *xyuvav, int32_t N, int32_t dimx, int32_t dimy,
+                           float meter_per_spacing, float radius, int32_t *ruv /*[cap][2]*/, int32_t cap,
+                           int32_t *nn);
+
+/* ---- a9-a10: QM pseudo-smoothing.  Replaces get_dpf_pseudosmoothing (MIMC_module.h:58,
+ *      MIMC_module.c:1986-2312) incl. quadfit2 / GMA_double_inv.  In place on dpf, dpf_dx, dpf_dy
+ *      ([dimy][dimx]).  mvn = candidates padded to [N][Kmax][5] (mean_u, mean_v, var_u, var_v,
+ *      fraction) with nclus[N] valid rows (flattening of `GMA_float **mvn_dp`).
+ *      max_sweeps: the reference loops while NOI<=100, i.e. at most 101 sweeps -> pass 101 for
+ *      drop-in behaviour (BASELINE config C5 passes 10).  sweeps_done may be NULL. ------------- */
+int mimc3_qm_pseudosmooth(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,
+                          const int32_t *ruv, int32_t nn, const float *mvn, int32_t Kmax, const int32_t *nclus,
+                          const double *xyuvav, int32_t max_sweeps, int32_t *sweeps_done);
+/* Device-resident variant: d_work must hold mimc3_qm_workspace_bytes(dimy*dimx, max_sweeps) bytes.
+ * Runs up to max_sweeps sweeps back-to-back with device-side early-out (no host sync). */
+int64_t mimc3_qm_workspace_bytes(int32_t ngrid, int32_t max_sweeps);
+int mimc3_qm_pseudosmooth_dev(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *d_dpf, float *d_dpf_dx,
+                              float *d_dpf_dy, const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax,
+                              const int32_t *d_nclus, const double *d_xyuvav, int32_t max_sweeps,
+                              void *d_work, int32_t *d_sweeps_done, void *stream);
+
+/* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
+ *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */
+int mimc3_ctx_enable_timing(mimc3_ctx *ctx, int32_t on);
+int mimc3_ctx_last_kernel_ms(mimc3_ctx *ctx, float *ms);
+
+const char *mimc3_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMC3_HIP_H */

@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's entry points for the hot path, over the C ABI
+(include/mimc3_hip.h -> csrc/libmimc3_hip.so).
+
+Names and argument meaning follow the reference (MIMC_module.h:41-58):
+    get_uv_pivot, matching_ncc_dlc_2, get_ruv_neighbor, get_dpf_pseudosmoothing
+with the ragged ``GMA_int32 **uv_pivot`` flattened to CSR ``(piv_off, piv_uv)`` and the ragged
+``GMA_float **mvn_dp`` padded to ``[N][Kmax][5]`` + ``nclus[N]``.
+
+Importing this module loads the HIP library and raises if it is missing: there is no CPU fallback
+(the CPU restatement lives in oracle/ and is test infrastructure only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmimc3_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not built. Run `make -C mimc3_amd/csrc` (or python -c 'import __graft_entry__ as g; g.build()'). "
+        "mimc3_amd has no CPU fallback.")
+_lib = C.CDLL(LIB_PATH)
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+# every symbol include/mimc3_hip.h declares (checked by tests/test_capi_symbols.py)
+_lib.mimc3_last_error.restype = C.c_char_p
+_lib.mimc3_version.restype = C.c_char_p
+_lib.mimc3_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+_lib.mimc3_ctx_destroy.argtypes = [_vp]
+_lib.mimc3_ctx_destroy.restype = None
+_lib.mimc3_ctx_set_images.argtypes = [_vp, _f32p, _f32p, C.c_int32, C.c_int32]
+_lib.mimc3_ctx_set_images_dev.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_get_uv_pivot.argtypes = [_f64p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                    C.c_int32, _i64p, _vp, C.c_int64, C.POINTER(C.c_int64)]
+_lib.mimc3_match_ncc_dlc.argtypes = [_vp, _f64p, C.c_int32, _i32p, _i32p, _i64p, C.c_int32, C.c_int32, _f32p]
+_lib.mimc3_match_ncc_dlc_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, _vp, _vp]
+_lib.mimc3_pivot_extent.argtypes = [_i32p, _i64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32)]
+_lib.mimc3_get_ruv_neighbor.argtypes = [_f64p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _i32p, C.c_int32,
+                                        C.POINTER(C.c_int32)]
+_lib.mimc3_qm_pseudosmooth.argtypes = [_vp, C.c_int32, C.c_int32, _i32p, _f32p, _f32p, _i32p, C.c_int32, _f32p,
+                                       C.c_int32, _i32p, _f64p, C.c_int32, C.POINTER(C.c_int32)]
+_lib.mimc3_qm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+_lib.mimc3_qm_workspace_bytes.restype = C.c_int64
+_lib.mimc3_qm_pseudosmooth_dev.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp,
+                                           _vp, C.c_int32, _vp, _vp, _vp]
+_lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
+_lib.mimc3_ctx_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
+
+
+class Mimc3Error(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = _lib.mimc3_last_error().decode(errors="replace")
+        super().__init__(f"{where}: rc={code}: {msg}")
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise Mimc3Error(rc, where)
+
+
+def version():
+    return _lib.mimc3_version().decode()
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side geometry (no GPU needed)
+# ---------------------------------------------------------------------------------------------
+def get_uv_pivot(xyuvav, dt, mpp, ocw, H, W, aw_sf=1.8, aw_cre=10.0):
+    """get_uv_pivot (MIMC_module.c:543-602) -> CSR (piv_off int64[N+1], piv_uv int32[P][2])."""
+    xy = np.ascontiguousarray(xyuvav, np.float64)
+    n = xy.shape[0]
+    off = np.zeros(n + 1, np.int64)
+    tot = C.c_int64(0)
+    _check(_lib.mimc3_get_uv_pivot(xy, n, dt, mpp, aw_sf, aw_cre, ocw, H, W, off, None, 0, C.byref(tot)), "get_uv_pivot")
+    uv = np.zeros((tot.value, 2), np.int32)
+    _check(_lib.mimc3_get_uv_pivot(xy, n, dt, mpp, aw_sf, aw_cre, ocw, H, W, off, uv.ctypes.data_as(_vp), tot.value,
+                                   C.byref(tot)), "get_uv_pivot")
+    return off, uv
+
+
+def pivot_extent(piv_off, piv_uv):
+    mn, mu, mv = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    off = np.ascontiguousarray(piv_off, np.int64)
+    _check(_lib.mimc3_pivot_extent(np.ascontiguousarray(piv_uv, np.int32), off, off.shape[0] - 1, C.byref(mn), C.byref(mu),
+                                   C.byref(mv)), "pivot_extent")
+    return mn.value, mu.value, mv.value
+
+
+def get_ruv_neighbor(xyuvav, dimx, dimy, meter_per_spacing, radius, cap=4096):
+    """get_ruv_neighbor (MIMC_module.c:1266-1327) -> int32[nn][2]."""
+    xy = np.ascontiguousarray(xyuvav, np.float64)
+    ruv = np.zeros((cap, 2), np.int32)
+    nn = C.c_int32(0)
+    _check(_lib.mimc3_get_ruv_neighbor(xy, xy.shape[0], dimx, dimy, meter_per_spacing, radius, ruv, cap, C.byref(nn)),
+           "get_ruv_neighbor")
+    return np.ascontiguousarray(ruv[:nn.value])
+
+
+# ---------------------------------------------------------------------------------------------
+# device context
+# ---------------------------------------------------------------------------------------------
+class Context:
+    """Owns a HIP stream and the resident image pair (mimc3_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        _check(_lib.mimc3_ctx_create(device, C.byref(self._h)), "ctx_create")
+        self.device = device
+        self.H = self.W = 0
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            _lib.mimc3_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- images -------------------------------------------------------------------------------
+    def set_images(self, i0, i1):
+        i0 = np.ascontiguousarray(i0, np.float32)
+        i1 = np.ascontiguousarray(i1, np.float32)
+        assert i0.shape == i1.shape and i0.ndim == 2
+        self.H, self.W = i0.shape
+        _check(_lib.mimc3_ctx_set_images(self._h, i0, i1, self.H, self.W), "ctx_set_images")
+
+    def set_images_dev(self, d_i0, d_i1, H, W, keep=None):
+        """d_i0/d_i1: integer device addresses (e.g. torch tensor.data_ptr()); keep = objects to hold."""
+        self.H, self.W = H, W
+        self._keep = keep
+        _check(_lib.mimc3_ctx_set_images_dev(self._h, d_i0, d_i1, H, W), "ctx_set_images_dev")
+
+    # -- matcher ------------------------------------------------------------------------------
+    def matching_ncc_dlc_2(self, xyuvav, offset, piv_off, piv_uv, ocw, swap=False):
+        """matching_ncc_dlc_2 (MIMC_module.c:805-842) on the resident pair -> float32[N][3].
+        swap=True = the CLI's "swapped forward" pass (chip from i1, window from i0)."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        n = xy.shape[0]
+        out = np.empty((n, 3), np.float32)
+        _check(_lib.mimc3_match_ncc_dlc(self._h, xy, n, np.ascontiguousarray(offset, np.int32),
+                                        np.ascontiguousarray(piv_uv, np.int32), np.ascontiguousarray(piv_off, np.int64),
+                                        ocw, 1 if swap else 0, out), "matching_ncc_dlc_2")
+        return out
+
+    def matching_ncc_dlc_2_dev(self, d_xyuvav, n, offset, d_piv_uv, d_piv_off, extent, ocw, d_out, stream=0, swap=False):
+        """Device-pointer variant (enqueue only). extent = pivot_extent(...) = (max_npiv, max|u|, max|v|)."""
+        mn, mu, mv = extent
+        _check(_lib.mimc3_match_ncc_dlc_dev(self._h, d_xyuvav, n, int(offset[0]), int(offset[1]), d_piv_uv, d_piv_off,
+                                            mn, mu, mv, ocw, 1 if swap else 0, d_out, stream), "matching_ncc_dlc_2_dev")
+
+    # -- QM -----------------------------------------------------------------------------------
+    def get_dpf_pseudosmoothing(self, dpf, dpf_dx, dpf_dy, ruv, mvn, nclus, xyuvav, max_sweeps=101):
+        """get_dpf_pseudosmoothing (MIMC_module.c:1986-2312). Returns (dpf, dx, dy, sweeps); inputs untouched."""
+        dimy, dimx = dpf.shape
+        d = np.array(dpf, np.int32, order="C")
+        x = np.array(dpf_dx, np.float32, order="C")
+        y = np.array(dpf_dy, np.float32, order="C")
+        ruv = np.ascontiguousarray(ruv, np.int32)
+        mvn = np.ascontiguousarray(mvn, np.float32)
+        sw = C.c_int32(0)
+        _check(_lib.mimc3_qm_pseudosmooth(self._h, dimy, dimx, d.reshape(-1), x.reshape(-1), y.reshape(-1), ruv,
+                                          ruv.shape[0], mvn, mvn.shape[1], np.ascontiguousarray(nclus, np.int32),
+                                          np.ascontiguousarray(xyuvav, np.float64), max_sweeps, C.byref(sw)),
+               "get_dpf_pseudosmoothing")
+        return d, x, y, sw.value
+
+    def qm_workspace_bytes(self, ngrid, max_sweeps):
+        return int(_lib.mimc3_qm_workspace_bytes(ngrid, max_sweeps))
+
+    def get_dpf_pseudosmoothing_dev(self, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus, d_xyuvav,
+                                    max_sweeps, d_work, d_sweeps=None, stream=0):
+        _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
+                                              d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- timing -------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        _check(_lib.mimc3_ctx_enable_timing(self._h, 1 if on else 0), "enable_timing")
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(_lib.mimc3_ctx_last_kernel_ms(self._h, C.byref(ms)), "last_kernel_ms")
+        return float(ms.value)

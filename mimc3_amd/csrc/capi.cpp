@@ -1,0 +1,281 @@
+// capi.cpp -- the C ABI of libmimc3_hip.so (include/mimc3_hip.h): context, resident images,
+// host-buffer (drop-in) and device-buffer (resident) entry points of the matcher and QM paths.
+// No CPU fallback: every compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mimc3_hip.h"
+#include "host_util.h"
+#include "match_kernel.h"
+#include "qm_kernel.h"
+
+namespace mimc3 {
+static thread_local std::string g_err;
+int fail(int code, const char *msg) { g_err = msg ? msg : ""; return code; }
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+static int hip_fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e > 0 ? (int)e : MIMC3_ENODEV;
+}
+}  // namespace mimc3
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) return mimc3::hip_fail(e_, #expr);             \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct mimc3_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // owned; host-buffer entry points run here
+    const float *d_i0 = nullptr, *d_i1 = nullptr;
+    DevBuf own_i0, own_i1;              // used when images were uploaded from the host
+    int32_t H = 0, W = 0;
+    DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
+    DevBuf qm_io, qm_work;              // QM staging / workspace
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+static float min_dn_threshold()
+{
+    // smallest f32 t with (double)t >= 1e-10: "x >= MIN_DN" (f32 promoted to f64, MIMC_module.c:21,:723)
+    // is then exactly "x >= t" in f32.
+    float t = (float)1e-10;
+    if ((double)t < 1e-10) t = std::nextafterf(t, 1.0f);
+    return t;
+}
+
+extern "C" const char *mimc3_last_error(void) { return mimc3::g_err.c_str(); }
+extern "C" const char *mimc3_version(void) { return "mimc3_hip 0.1.0 (gfx950)"; }
+
+extern "C" int mimc3_ctx_create(int device, mimc3_ctx **out)
+{
+    if (!out) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return mimc3::fail(MIMC3_ENODEV, "mimc3_ctx_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mimc3_ctx *c = new mimc3_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return mimc3::hip_fail(e, "hipStreamCreate"); }
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    *out = c;
+    return 0;
+}
+
+extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->own_i0.release(); c->own_i1.release();
+    c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
+    c->qm_io.release(); c->qm_work.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *i1, int32_t H, int32_t W)
+{
+    if (!c || !i0 || !i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * (size_t)H * W;
+    HIP_TRY(c->own_i0.reserve(bytes));
+    HIP_TRY(c->own_i1.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(c->own_i0.p, i0, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->own_i1.p, i1, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->d_i0 = static_cast<const float *>(c->own_i0.p);
+    c->d_i1 = static_cast<const float *>(c->own_i1.p);
+    c->H = H; c->W = W;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
+{
+    if (!c || !d_i0 || !d_i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_dev: bad argument");
+    c->d_i0 = d_i0; c->d_i1 = d_i1; c->H = H; c->W = W;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_enable_timing(mimc3_ctx *c, int32_t on)
+{
+    if (!c) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_enable_timing: ctx is NULL");
+    c->timing = on != 0; c->timed = false;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_last_kernel_ms(mimc3_ctx *c, float *ms)
+{
+    if (!c || !ms) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_last_kernel_ms: bad argument");
+    if (!c->timed) return mimc3::fail(MIMC3_ESTATE, "mimc3_ctx_last_kernel_ms: no timed launch recorded");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matcher
+// ---------------------------------------------------------------------------------------------
+extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int32_t N, int32_t off_u, int32_t off_v,
+                                       const int32_t *d_piv_uv, const int64_t *d_piv_off, int32_t max_npiv,
+                                       int32_t max_abs_piv_u, int32_t max_abs_piv_v, int32_t ocw, int32_t swap,
+                                       float *d_out, void *stream)
+{
+    if (!c || !d_xyuvav || !d_piv_uv || !d_piv_off || !d_out || N <= 0 || max_npiv < 1 || max_abs_piv_u < 0 || max_abs_piv_v < 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_dev: bad argument");
+    if (ocw < 1) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_dev: ocw must be >= 1");
+    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_dev: images not set");
+    HIP_TRY(hipSetDevice(c->device));
+    mimc3::MatchArgs a{};
+    a.i0 = c->d_i0; a.i1 = c->d_i1; a.H = c->H; a.W = c->W;
+    a.xyuvav = d_xyuvav; a.N = N; a.off_u = off_u; a.off_v = off_v;
+    a.piv_uv = d_piv_uv; a.piv_off = d_piv_off; a.ocw = ocw; a.swap = swap ? 1 : 0;
+    a.thr = min_dn_threshold();
+    a.out = d_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
+    hipError_t e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+    if (e != hipSuccess) return mimc3::hip_fail(e, "match kernel launch");
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
+    return 0;
+}
+
+extern "C" int mimc3_match_ncc_dlc(mimc3_ctx *c, const double *xyuvav, int32_t N, const int32_t offset[2],
+                                   const int32_t *piv_uv, const int64_t *piv_off, int32_t ocw, int32_t swap, float *out)
+{
+    if (!c || !xyuvav || !offset || !piv_uv || !piv_off || !out || N <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc: bad argument");
+    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc: images not set");
+    // The reference reads the chip without any bounds check (MIMC_module.c:852) and overflows on an
+    // empty pivot list (:589-591).  Refuse those inputs instead of reproducing undefined behaviour.
+    for (int32_t g = 0; g < N; ++g) {
+        const int32_t u0 = (int32_t)xyuvav[6 * (size_t)g + 2], v0 = (int32_t)xyuvav[6 * (size_t)g + 3];
+        if (u0 - ocw < 0 || u0 + ocw >= c->W || v0 - ocw < 0 || v0 + ocw >= c->H)
+            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc: grid point " + std::to_string(g) + " chip leaves the image");
+    }
+    int32_t mn = 0, mu = 0, mv = 0;
+    int rc = mimc3_pivot_extent(piv_uv, piv_off, N, &mn, &mu, &mv);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t P = (size_t)piv_off[N];
+    HIP_TRY(c->xy.reserve(sizeof(double) * 6 * (size_t)N));
+    HIP_TRY(c->puv.reserve(sizeof(int32_t) * 2 * P));
+    HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + 1)));
+    HIP_TRY(c->out.reserve(sizeof(float) * 3 * (size_t)N));
+    HIP_TRY(hipMemcpyAsync(c->xy.p, xyuvav, sizeof(double) * 6 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->puv.p, piv_uv, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->poff.p, piv_off, sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, c->stream));
+    rc = mimc3_match_ncc_dlc_dev(c, static_cast<const double *>(c->xy.p), N, offset[0], offset[1],
+                                 static_cast<const int32_t *>(c->puv.p), static_cast<const int64_t *>(c->poff.p), mn, mu, mv,
+                                 ocw, swap, static_cast<float *>(c->out.p), c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->out.p, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// QM pseudo-smoothing
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t mimc3_qm_workspace_bytes(int32_t ngrid, int32_t max_sweeps)
+{
+    if (ngrid <= 0 || max_sweeps <= 0) return 0;
+    return mimc3::qm_workspace_bytes(ngrid, max_sweeps);
+}
+
+extern "C" int mimc3_qm_pseudosmooth_dev(mimc3_ctx *c, int32_t dimy, int32_t dimx, int32_t *d_dpf, float *d_dpf_dx,
+                                         float *d_dpf_dy, const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax,
+                                         const int32_t *d_nclus, const double *d_xyuvav, int32_t max_sweeps,
+                                         void *d_work, int32_t *d_sweeps_done, void *stream)
+{
+    if (!c || !d_dpf || !d_dpf_dx || !d_dpf_dy || !d_ruv || !d_mvn || !d_nclus || !d_xyuvav || !d_work ||
+        dimx <= 0 || dimy <= 0 || nn <= 0 || Kmax <= 0 || max_sweeps <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_qm_pseudosmooth_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    mimc3::QmArgs a{};
+    a.dimy = dimy; a.dimx = dimx; a.N = dimx * dimy;
+    a.dpf = d_dpf; a.dx = d_dpf_dx; a.dy = d_dpf_dy; a.ruv = d_ruv; a.nn = nn; a.mvn = d_mvn; a.Kmax = Kmax;
+    a.nclus = d_nclus; a.xyuvav = d_xyuvav; a.max_sweeps = max_sweeps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = mimc3::launch_qm(a, d_work, s);
+    if (e != hipSuccess) return mimc3::hip_fail(e, "qm kernel launch");
+    if (d_sweeps_done) {
+        const char *flags = static_cast<const char *>(d_work) + mimc3::qm_flags_offset_bytes(a.N);
+        HIP_TRY(hipMemcpyAsync(d_sweeps_done, flags + 4 * mimc3::kQmSweeps, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+extern "C" int mimc3_qm_pseudosmooth(mimc3_ctx *c, int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,
+                                     const int32_t *ruv, int32_t nn, const float *mvn, int32_t Kmax, const int32_t *nclus,
+                                     const double *xyuvav, int32_t max_sweeps, int32_t *sweeps_done)
+{
+    if (!c || !dpf || !dpf_dx || !dpf_dy || !ruv || !mvn || !nclus || !xyuvav || dimx <= 0 || dimy <= 0 || nn <= 0 ||
+        Kmax <= 0 || max_sweeps <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_qm_pseudosmooth: bad argument");
+    const size_t N = (size_t)dimx * dimy;
+    for (size_t i = 0; i < N; ++i)
+        if (nclus[i] < 0 || nclus[i] > Kmax || dpf[i] >= Kmax)
+            return mimc3::fail(MIMC3_EINVAL, "mimc3_qm_pseudosmooth: cluster count/id exceeds Kmax");
+    HIP_TRY(hipSetDevice(c->device));
+    // one staging buffer, 256-byte aligned sections
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_dpf = 0, o_dx = o_dpf + al(4 * N), o_dy = o_dx + al(4 * N), o_ruv = o_dy + al(4 * N),
+                 o_mvn = o_ruv + al(8 * (size_t)nn), o_ncl = o_mvn + al(20 * N * Kmax), o_xy = o_ncl + al(4 * N),
+                 o_swp = o_xy + al(48 * N), total = o_swp + 256;
+    HIP_TRY(c->qm_io.reserve(total));
+    HIP_TRY(c->qm_work.reserve((size_t)mimc3::qm_workspace_bytes((int32_t)N, max_sweeps)));
+    char *b = static_cast<char *>(c->qm_io.p);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_dpf, dpf, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_dx, dpf_dx, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_dy, dpf_dy, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_ruv, ruv, 8 * (size_t)nn, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_mvn, mvn, 20 * N * Kmax, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_ncl, nclus, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_xy, xyuvav, 48 * N, hipMemcpyHostToDevice, s));
+    int rc = mimc3_qm_pseudosmooth_dev(c, dimy, dimx, reinterpret_cast<int32_t *>(b + o_dpf), reinterpret_cast<float *>(b + o_dx),
+                                       reinterpret_cast<float *>(b + o_dy), reinterpret_cast<const int32_t *>(b + o_ruv), nn,
+                                       reinterpret_cast<const float *>(b + o_mvn), Kmax, reinterpret_cast<const int32_t *>(b + o_ncl),
+                                       reinterpret_cast<const double *>(b + o_xy), max_sweeps, c->qm_work.p,
+                                       reinterpret_cast<int32_t *>(b + o_swp), s);
+    if (rc) return rc;
+    int32_t sw = 0;
+    HIP_TRY(hipMemcpyAsync(dpf, b + o_dpf, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dpf_dx, b + o_dx, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dpf_dy, b + o_dy, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&sw, b + o_swp, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (sweeps_done) *sweeps_done = sw;
+    return 0;
+}

@@ -1,0 +1,142 @@
+// host_geometry.cpp -- host-side (CPU) pieces of the hot path that stay on the host:
+//   * the DLC pivot generator  (replaces get_uv_pivot,     MIMC_module.c:543-602)
+//   * the neighbour offset list (replaces get_ruv_neighbor, MIMC_module.c:1266-1327)
+// Both are O(N) integer/trig bookkeeping whose results must equal the reference's libm-based
+// float/double mix bit for bit, so they run on the host with the same libm.
+// Every implicit C promotion of the reference is spelled out here as an explicit cast.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include "../../include/mimc3_hip.h"
+#include "host_util.h"
+
+namespace {
+
+// Direction/length of one point's corridor (MIMC_module.c:559-573).
+struct Corridor {
+    float incr_u, incr_v, norm_incr;
+    double length;
+    Corridor(double vx, double vy, float dt, float mpp, float aw_sf, float aw_cre)
+    {
+        const float theta = (float)std::atan2(vy, vx);
+        float cu = (float)std::cos((double)theta);
+        float su = (float)std::sin((double)theta);
+        // normalise so the larger component becomes +-1.  The reference divides the SECOND
+        // component by the already-normalised first one in the |cos|>|sin| branch (T5).
+        if (std::fabs((double)cu) > std::fabs((double)su)) {
+            cu = (float)((double)cu / std::fabs((double)cu));
+            su = (float)((double)su / std::fabs((double)cu));
+        } else {
+            cu = (float)((double)cu / std::fabs((double)su));
+            su = (float)((double)su / std::fabs((double)su));
+        }
+        incr_u = cu; incr_v = su;
+        const float sq = cu * cu + su * su;                 // f32 expression
+        norm_incr = (float)std::sqrt((double)sq);
+        length = std::sqrt(vx * vx + vy * vy) / (double)mpp / 365.0 * (double)dt * (double)aw_sf + (double)aw_cre + 1.0;
+    }
+    // number of pivots that stay inside the image +- ocw and inside the corridor length (:576-585)
+    int32_t count(double gu, double gv, int32_t ocw, int32_t H, int32_t W) const
+    {
+        const float fu = (float)gu, fv = (float)gv, fo = (float)ocw;
+        const float wmax = (float)(W - 1), hmax = (float)(H - 1);
+        float u = 0.0f, v = 0.0f;
+        int32_t n = 0;
+        for (;;) {
+            const bool inside = (u + fu - fo > 0.0f) && (u + fu + fo < wmax) && (v + fv - fo > 0.0f) && (v + fv + fo < hmax);
+            if (!inside) break;
+            if (!(length > (double)norm_incr * (double)n)) break;
+            ++n; u += incr_u; v += incr_v;
+        }
+        return n;
+    }
+    void fill(int32_t n, int32_t *uv) const
+    {
+        float u = 0.0f, v = 0.0f;
+        uv[0] = 0; uv[1] = 0;
+        for (int32_t k = 1; k < n; ++k) {
+            u += incr_u; v += incr_v;
+            uv[2 * k] = (int32_t)((double)u + 0.5);          // C truncation toward zero (:596)
+            uv[2 * k + 1] = -(int32_t)((double)v + 0.5);     // image v is down, a-priori vy is north (:597)
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre,
+                                  int32_t ocw, int32_t H, int32_t W, int64_t *piv_off, int32_t *piv_uv,
+                                  int64_t cap, int64_t *total)
+{
+    if (!xyuvav || !piv_off || !total || N <= 0 || ocw < 1 || H <= 0 || W <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_uv_pivot: bad argument");
+    int64_t tot = 0;
+    bool empty = false;
+    piv_off[0] = 0;
+    for (int32_t g = 0; g < N; ++g) {
+        const double *r = xyuvav + 6 * (size_t)g;
+        const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
+        const int32_t n = c.count(r[2], r[3], ocw, H, W);
+        if (n <= 0) empty = true;
+        tot += n > 0 ? n : 0;
+        piv_off[g + 1] = tot;
+    }
+    *total = tot;
+    if (empty) return mimc3::fail(MIMC3_EBOUNDS, "mimc3_get_uv_pivot: a grid point has zero pivots (too close to the image edge)");
+    if (!piv_uv) return 0;
+    if (cap < tot) return mimc3::fail(MIMC3_ECAP, "mimc3_get_uv_pivot: pivot capacity too small");
+    for (int32_t g = 0; g < N; ++g) {
+        const double *r = xyuvav + 6 * (size_t)g;
+        const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
+        c.fill((int32_t)(piv_off[g + 1] - piv_off[g]), piv_uv + 2 * piv_off[g]);
+    }
+    return 0;
+}
+
+extern "C" int mimc3_pivot_extent(const int32_t *piv_uv, const int64_t *piv_off, int32_t N, int32_t *max_npiv,
+                                  int32_t *max_abs_u, int32_t *max_abs_v)
+{
+    if (!piv_uv || !piv_off || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_pivot_extent: bad argument");
+    int32_t mn = 0, mu = 0, mv = 0;
+    for (int32_t g = 0; g < N; ++g) {
+        const int64_t n = piv_off[g + 1] - piv_off[g];
+        if (n < 1) return mimc3::fail(MIMC3_EBOUNDS, "mimc3_pivot_extent: a grid point has zero pivots");
+        if (n > mn) mn = (int32_t)n;
+        const int32_t *last = piv_uv + 2 * (piv_off[g + 1] - 1);   // only the LAST pivot sizes the window (:863-864)
+        const int32_t au = std::abs(last[0]), av = std::abs(last[1]);
+        if (au > mu) mu = au;
+        if (av > mv) mv = av;
+    }
+    if (max_npiv) *max_npiv = mn;
+    if (max_abs_u) *max_abs_u = mu;
+    if (max_abs_v) *max_abs_v = mv;
+    return 0;
+}
+
+extern "C" int mimc3_get_ruv_neighbor(const double *xyuvav, int32_t N, int32_t dimx, int32_t dimy,
+                                      float meter_per_spacing, float radius, int32_t *ruv, int32_t cap, int32_t *nn)
+{
+    if (!xyuvav || !ruv || !nn || dimx <= 0 || dimy <= 0 || (int64_t)dimx * dimy > N)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_ruv_neighbor: bad argument");
+    // The reference builds x from grid row 0 and y from grid column 0 as f32 mesh grids and keeps
+    // every node within radius*meter_per_spacing of the CENTRE node (:1277-1311).
+    const int32_t cu = dimx / 2, cv = dimy / 2;
+    const float cx = (float)xyuvav[6 * (size_t)cu], cy = (float)xyuvav[6 * (size_t)cv * dimx + 1];
+    const float rr = radius * meter_per_spacing;
+    const float lim = rr * rr;
+    int32_t cnt = 0;
+    for (int32_t v = 0; v < dimy; ++v) {
+        const float ddy = (float)xyuvav[6 * (size_t)v * dimx + 1] - cy;
+        for (int32_t u = 0; u < dimx; ++u) {
+            const float ddx = (float)xyuvav[6 * (size_t)u] - cx;
+            const float sq = ddx * ddx + ddy * ddy;
+            if (sq <= lim) {
+                if (cnt < cap) { ruv[2 * cnt] = u - cu; ruv[2 * cnt + 1] = v - cv; }
+                ++cnt;
+            }
+        }
+    }
+    *nn = cnt;
+    if (cnt > cap) return mimc3::fail(MIMC3_ECAP, "mimc3_get_ruv_neighbor: capacity too small");
+    return 0;
+}

@@ -1,0 +1,107 @@
+"""GPU: the HIP matcher (through the C ABI) against the committed golden vectors and the oracle.
+Bar: bit-exact (out[N,3] as uint32 words; NaN == NaN) for integer-DN inputs."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, golden_files, load_match_golden
+from mimc3_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from mimc3_amd import api as a
+    return a
+
+
+@pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
+def test_golden(api, path):
+    g = load_match_golden(path)
+    H, W = g["i0"].shape
+    off, uv = api.get_uv_pivot(g["xyuvav"], g["dt"], g["mpp"], g["ocw"], H, W)
+    with api.Context(0) as ctx:
+        ctx.set_images(g["i0"], g["i1"])
+        out = ctx.matching_ncc_dlc_2(g["xyuvav"], g["offset"], off, uv, g["ocw"])
+        assert_bits_equal(out, g["out"], "forward")
+        out_sw = ctx.matching_ncc_dlc_2(g["xyuvav"], -g["offset"], off, -uv, g["ocw"], swap=True)
+        assert_bits_equal(out_sw, g["out_swapped"], "swapped")
+
+
+SMALL = [
+    dict(seed=31, shift=(3, -2), angle_deg=10.0, ocw=7),
+    dict(seed=32, shift=(-3, 1), angle_deg=170.0, ocw=12, noise_dn=3, null_frac=0.08),
+    dict(seed=33, shift=(0, 4), angle_deg=-88.0, ocw=9, subpixel=(0.5, 0.25), bits=16),
+    dict(seed=34, shift=(2, 2), angle_deg=-40.0, ocw=15, speed=2500.0, h=220, w=230, offset=(-1, 2)),
+    dict(seed=35, shift=(6, -6), angle_deg=45.0, ocw=16, speed=1806.0, h=260, w=260, noise_dn=2, null_frac=0.03),
+    dict(seed=36, shift=(1, 0), angle_deg=0.0, ocw=30, speed=700.0, h=300, w=320, dimx=5, dimy=4),   # 61x61 chip
+    dict(seed=37, shift=(-2, -5), angle_deg=112.0, ocw=40, speed=900.0, h=360, w=340, dimx=4, dimy=4),  # 81x81 chip
+]
+
+
+@pytest.mark.parametrize("kw", SMALL, ids=lambda k: f"seed{k['seed']}_ocw{k['ocw']}")
+def test_vs_oracle(api, oracle, kw):
+    c = synth.make_small(**kw)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+    assert_bits_equal(got, want)
+
+
+def test_c1_config_vs_oracle(api, oracle):
+    """BASELINE configs[0]: 512^2, 1,024 points, 33x33 chip / 65x65 window."""
+    c = synth.make_case("C1")
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+    assert_bits_equal(got, want)
+    ok = got[:, 2] > 0.5
+    assert ok.mean() > 0.9
+    assert np.abs(np.median(got[ok, 0]) - c.shift[0]) < 0.2 and np.abs(np.median(got[ok, 1]) - c.shift[1]) < 0.2
+
+
+def test_float_images_within_tolerance(api, oracle):
+    """Non-integer DN: f64 sums are no longer exact, so the summation order shows in the last bits.
+    north_star tolerance: |d(u,v)| <= 1e-4 px, identical invalid mask."""
+    c = synth.make_small(seed=41, shift=(2, -3), angle_deg=-60.0, ocw=11, null_frac=0.04)
+    rng = np.random.default_rng(1)
+    i0 = (c.i0 * np.float32(0.731) + np.where(c.i0 > 0, rng.random(c.i0.shape, dtype=np.float32), 0)).astype(np.float32)
+    i1 = (c.i1 * np.float32(0.731) + np.where(c.i1 > 0, rng.random(c.i1.shape, dtype=np.float32), 0)).astype(np.float32)
+    H, W = i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(i0, i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(i0, i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-4
+
+
+def test_edge_cases(api):
+    c = synth.make_small(seed=51)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    with api.Context(0) as ctx:
+        with pytest.raises(api.Mimc3Error):        # images not set
+            ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        ctx.set_images(c.i0, c.i1)
+        bad = c.xyuvav.copy()
+        bad[0, 2] = 2.0                            # chip would leave the image: refused, not UB
+        with pytest.raises(api.Mimc3Error) as e:
+            ctx.matching_ncc_dlc_2(bad, c.offset, off, uv, c.ocw)
+        assert e.value.code == -2
+        # all-null pair -> every point invalid (NaN, NaN, -3)
+        ctx.set_images(np.zeros_like(c.i0), np.zeros_like(c.i1))
+        out = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert np.isnan(out[:, :2]).all() and (out[:, 2] == -3).all()
+        # single grid point
+        ctx.set_images(c.i0, c.i1)
+        one = ctx.matching_ncc_dlc_2(c.xyuvav[:1], c.offset, off[:2], uv[:off[1]], c.ocw)
+        full = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert_bits_equal(one, full[:1])
