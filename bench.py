@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
+    ap.add_argument("--path", default="auto", choices=["auto", "general"],
+                    help="auto: exact u8 kernel when the pair is 8-bit integral; general: force the f32/f64 kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -92,7 +94,10 @@ def main():
     d_all = torch.empty((world * n, 3), dtype=torch.float32, device=dev) if world > 1 else None
 
     ctx = api.Context(local_rank)
-    ctx.set_images_dev(d_i0.data_ptr(), d_i1.data_ptr(), H, W, keep=(d_i0, d_i1))
+    t_prep0 = time.perf_counter()
+    ctx.set_images_dev(d_i0.data_ptr(), d_i1.data_ptr(), H, W, keep=(d_i0, d_i1))   # builds + proves the u8 planes
+    t_prep = time.perf_counter() - t_prep0
+    ctx.set_path(args.path)
     stream = torch.cuda.current_stream()
 
     def step(ev=None):
@@ -132,7 +137,10 @@ def main():
             "metric": "grid-points/s (DLC NCC match)", "value": value, "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 pixels, f64 accumulate", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("u8 pixels, exact u32 dot4 sums, f64 NCC" if ctx.last_path() == "u8_exact"
+                      else "f32 pixels, f32 products, f64 sums and NCC"),
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points per GPU "
                                    f"({case.dimx}x{case.dimy}), ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), "
                                    f"{extent[0]} pivots max, window up to {2 * (extent[1] + case.ocw + 2) + 1}^2",
@@ -140,8 +148,9 @@ def main():
                        "parallelism": f"grid-point shard x{world}" + (", RCCL all-gather of [N,3]" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "match_ncc_dlc_f32", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "h2d_images_s": t_h2d,
+                         "kernel": "match_ncc_dlc_u8" if ctx.last_path() == "u8_exact" else "match_ncc_dlc_f32",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
         }
         got = d_out.cpu().numpy()
         valid = got[:, 2] > -2.5

@@ -52,6 +52,8 @@ _lib.mimc3_qm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
 _lib.mimc3_qm_workspace_bytes.restype = C.c_int64
 _lib.mimc3_qm_pseudosmooth_dev.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp,
                                            _vp, C.c_int32, _vp, _vp, _vp]
+_lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
+_lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
 
@@ -191,6 +193,14 @@ class Context:
                                     max_sweeps, d_work, d_sweeps=None, stream=0):
         _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
                                               d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- kernel selection ---------------------------------------------------------------------
+    def set_path(self, mode):
+        """0 = auto (exact u8 kernel when the pair is 8-bit integral), 1 = force the general f32 kernel."""
+        _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1}.get(mode, mode)), "set_path")
+
+    def last_path(self):
+        return {0: "general_f32", 1: "u8_exact"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
 
     # -- timing -------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -52,6 +52,11 @@ struct mimc3_ctx {
     const float *d_i0 = nullptr, *d_i1 = nullptr;
     DevBuf own_i0, own_i1;              // used when images were uploaded from the host
     int32_t H = 0, W = 0;
+    DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
+    int32_t Wp = 0;
+    bool u8_ok = false;                 // both images proven to be integers in [0,255]
+    int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
+    int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
     DevBuf qm_io, qm_work;              // QM staging / workspace
     bool timing = false;
@@ -96,6 +101,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
+    c->pl0.release(); c->pl1.release(); c->flag.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -103,6 +109,40 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+// Build the zero-bordered u8 planes and prove (on the device) that both images are 8-bit integral.
+// Runs once per image pair; the CLI then reuses the pair for 8 matcher passes (MIMC_main.c:261-300).
+static int prepare_u8(mimc3_ctx *c)
+{
+    c->u8_ok = false;
+    const int pad = mimc3::kU8Pad;
+    c->Wp = (c->W + 2 * pad + 3) & ~3;
+    const size_t bytes = (size_t)(c->H + 2 * pad) * c->Wp;
+    HIP_TRY(c->pl0.reserve(bytes));
+    HIP_TRY(c->pl1.reserve(bytes));
+    HIP_TRY(c->flag.reserve(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->pl0.p, 0, bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->pl1.p, 0, bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flag.p, 0, sizeof(int), c->stream));
+    HIP_TRY(mimc3::launch_prep_u8(c->d_i0, c->H, c->W, static_cast<unsigned char *>(c->pl0.p), c->Wp, pad,
+                                  static_cast<int *>(c->flag.p), c->stream));
+    HIP_TRY(mimc3::launch_prep_u8(c->d_i1, c->H, c->W, static_cast<unsigned char *>(c->pl1.p), c->Wp, pad,
+                                  static_cast<int *>(c->flag.p), c->stream));
+    int not_u8 = 1;
+    HIP_TRY(hipMemcpyAsync(&not_u8, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->u8_ok = (not_u8 == 0);
+    return 0;
+}
+
+extern "C" int mimc3_ctx_set_path(mimc3_ctx *c, int32_t mode)
+{
+    if (!c || mode < 0 || mode > 1) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
+    c->path_mode = mode;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_last_path(mimc3_ctx *c) { return c ? c->last_path : MIMC3_EINVAL; }
 
 extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *i1, int32_t H, int32_t W)
 {
@@ -117,14 +157,16 @@ extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *
     c->d_i0 = static_cast<const float *>(c->own_i0.p);
     c->d_i1 = static_cast<const float *>(c->own_i1.p);
     c->H = H; c->W = W;
-    return 0;
+    return prepare_u8(c);
 }
 
 extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
 {
     if (!c || !d_i0 || !d_i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_dev: bad argument");
     c->d_i0 = d_i0; c->d_i1 = d_i1; c->H = H; c->W = W;
-    return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());   // the caller's producer stream is unknown: make the pixels visible
+    return prepare_u8(c);
 }
 
 extern "C" int mimc3_ctx_enable_timing(mimc3_ctx *c, int32_t on)
@@ -164,7 +206,20 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     a.out = d_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
-    hipError_t e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+    const int reach_u = max_abs_piv_u + (off_u < 0 ? -off_u : off_u), reach_v = max_abs_piv_v + (off_v < 0 ? -off_v : off_v);
+    hipError_t e;
+    if (c->path_mode == 0 && c->u8_ok && mimc3::match_u8_supported(ocw, reach_u, reach_v)) {
+        mimc3::MatchU8Args u{};
+        u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
+        u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W;
+        u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
+        u.piv_uv = d_piv_uv; u.piv_off = d_piv_off; u.ocw = ocw; u.swap = swap ? 1 : 0; u.out = d_out;
+        e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+        c->last_path = 1;
+    } else {
+        e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+        c->last_path = 0;
+    }
     if (e != hipSuccess) return mimc3::hip_fail(e, "match kernel launch");
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
     return 0;

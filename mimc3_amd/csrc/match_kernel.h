@@ -23,6 +23,31 @@ struct MatchArgs {
     int32_t lds_chip_f, lds_win_f, lds_cell_f, lds_npiv;
 };
 
+// ---- exact-integer path for 8-bit imagery (match_u8_kernel.hip) -------------------------------
+constexpr int kU8Pad = 256;      // zero border (pixels) around the u8 planes; multiple of 4
+
+struct MatchU8Args {
+    const unsigned char *p0, *p1;   // zero-bordered u8 planes of i0, i1: pixel (u,v) at [(v+pad)*Wp + u+pad]
+    int32_t Wp, pad;                // plane pitch (bytes, % 4 == 0) and border
+    int32_t H, W;
+    const double *xyuvav;
+    int32_t N;
+    int32_t off_u, off_v;
+    const int32_t *piv_uv;
+    const int64_t *piv_off;
+    int32_t ocw, swap;
+    float *out;
+    // LDS carve, filled by the launcher
+    int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv;
+};
+
+// f32 image -> zero-bordered u8 plane (plane must be pre-zeroed); *d_flag is set to 1 if any pixel
+// is not an integer in [0,255] (then the u8 path must not be used for this image).
+hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, int Wp, int pad, int *d_flag, hipStream_t s);
+// instantiated chip sizes and border reach (|last pivot| + |CP offset| must fit in the border)
+bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v);
+hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
+
 // max_abs_u/v: max over points of |last pivot| per axis; max_npiv: max pivots per point.
 hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 

@@ -15,14 +15,25 @@ def api():
     return a
 
 
+U8_OCW = (7, 15, 16, 30, 32, 40)   # chip sizes the exact u8 kernel is instantiated for
+
+
+def expected_path(mode, i0, ocw):
+    u8 = mode == "auto" and ocw in U8_OCW and float(i0.max()) <= 255.0 and np.array_equal(i0, np.rint(i0))
+    return "u8_exact" if u8 else "general_f32"
+
+
+@pytest.mark.parametrize("mode", ["auto", "general"])
 @pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
-def test_golden(api, path):
+def test_golden(api, path, mode):
     g = load_match_golden(path)
     H, W = g["i0"].shape
     off, uv = api.get_uv_pivot(g["xyuvav"], g["dt"], g["mpp"], g["ocw"], H, W)
     with api.Context(0) as ctx:
         ctx.set_images(g["i0"], g["i1"])
+        ctx.set_path(mode)
         out = ctx.matching_ncc_dlc_2(g["xyuvav"], g["offset"], off, uv, g["ocw"])
+        assert ctx.last_path() == expected_path(mode, g["i0"], g["ocw"])
         assert_bits_equal(out, g["out"], "forward")
         out_sw = ctx.matching_ncc_dlc_2(g["xyuvav"], -g["offset"], off, -uv, g["ocw"], swap=True)
         assert_bits_equal(out_sw, g["out_swapped"], "swapped")
@@ -36,22 +47,33 @@ SMALL = [
     dict(seed=35, shift=(6, -6), angle_deg=45.0, ocw=16, speed=1806.0, h=260, w=260, noise_dn=2, null_frac=0.03),
     dict(seed=36, shift=(1, 0), angle_deg=0.0, ocw=30, speed=700.0, h=300, w=320, dimx=5, dimy=4),   # 61x61 chip
     dict(seed=37, shift=(-2, -5), angle_deg=112.0, ocw=40, speed=900.0, h=360, w=340, dimx=4, dimy=4),  # 81x81 chip
+    dict(seed=38, shift=(4, -3), angle_deg=38.0, ocw=7, speed=2000.0, noise_dn=2, null_frac=0.10, offset=(3, -2)),
+    dict(seed=39, shift=(-3, -3), angle_deg=135.0, ocw=15, speed=1700.0, h=240, w=250, null_frac=0.06),
+    dict(seed=40, shift=(5, 4), angle_deg=-38.0, ocw=32, speed=3000.0, h=400, w=420, dimx=5, dimy=5, noise_dn=1, null_frac=0.03),
+    dict(seed=42, shift=(0, -2), angle_deg=91.0, ocw=30, speed=1500.0, h=330, w=300, dimx=4, dimy=5, null_frac=0.05),
+    dict(seed=43, shift=(2, -2), angle_deg=45.0, ocw=16, speed=1806.0, h=200, w=210, margin=17, dimx=7, dimy=7),  # windows over the edge
 ]
 
 
+@pytest.mark.parametrize("mode", ["auto", "general"])
 @pytest.mark.parametrize("kw", SMALL, ids=lambda k: f"seed{k['seed']}_ocw{k['ocw']}")
-def test_vs_oracle(api, oracle, kw):
+def test_vs_oracle(api, oracle, kw, mode):
     c = synth.make_small(**kw)
     H, W = c.i0.shape
     off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
     want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
     with api.Context(0) as ctx:
         ctx.set_images(c.i0, c.i1)
+        ctx.set_path(mode)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert ctx.last_path() == expected_path(mode, c.i0, c.ocw)
+        sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
     assert_bits_equal(got, want)
+    assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
 
 
-def test_c1_config_vs_oracle(api, oracle):
+@pytest.mark.parametrize("mode", ["auto", "general"])
+def test_c1_config_vs_oracle(api, oracle, mode):
     """BASELINE configs[0]: 512^2, 1,024 points, 33x33 chip / 65x65 window."""
     c = synth.make_case("C1")
     H, W = c.i0.shape
@@ -59,6 +81,7 @@ def test_c1_config_vs_oracle(api, oracle):
     want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
     with api.Context(0) as ctx:
         ctx.set_images(c.i0, c.i1)
+        ctx.set_path(mode)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
     assert_bits_equal(got, want)
     ok = got[:, 2] > 0.5
@@ -81,6 +104,22 @@ def test_float_images_within_tolerance(api, oracle):
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= 1e-4
+
+
+def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
+    """The CLI's schedule: ocw 7, 15, 30, 40 forward + swapped on one resident pair (MIMC_main.c:261-300)."""
+    c = synth.make_small(seed=61, shift=(3, -3), angle_deg=45.0, ocw=40, speed=1200.0, h=330, w=340, dimx=5, dimy=5,
+                         noise_dn=2, null_frac=0.02)
+    H, W = c.i0.shape
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        for ocw in (7, 15, 30, 40):
+            off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+            fwd = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+            assert ctx.last_path() == "u8_exact"
+            assert_bits_equal(fwd, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, ocw), f"ocw{ocw} fwd")
+            sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
+            assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), f"ocw{ocw} swapped")
 
 
 def test_edge_cases(api):

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into a short text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+print(f"# rocprofv3 summary for {os.path.basename(out)}")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n## kernel stats (--kernel-trace --stats):", os.path.relpath(f, out))
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    for r in rows[:12]:
+        print("  {Name:60.60s} calls={Calls:>5s} total_ns={TotalDurationNs:>12s} avg_ns={AverageNs:>12s} pct={Percentage}".format(**r))
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    by = defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append(r)
+    print("\n## dispatch resources (first dispatch of each kernel)")
+    for k, v in by.items():
+        r = v[0]
+        keys = [c for c in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if c in r]
+        print("  %-60.60s " % k + " ".join(f"{c}={r[c]}" for c in keys))
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in rows:
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(f"\n## PMC {os.path.basename(d)} (mean per dispatch)")
+        for k, cs in acc.items():
+            for c, vals in cs.items():
+                print("  %-50.50s %-24s n=%d mean=%.6g" % (k, c, len(vals), sum(vals) / len(vals)))
