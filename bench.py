@@ -47,6 +47,11 @@ def main():
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
     ap.add_argument("--path", default="auto", choices=["auto", "general"],
                     help="auto: exact u8 kernel when the pair is 8-bit integral; general: force the f32/f64 kernel")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank matches its own lattice of the config's size (default); "
+                         "strong: the config's points are sharded across ranks (BASELINE configs[2])")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, default). gloo + MIMC3_BENCH_ONE_DEVICE=1 rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -62,21 +67,33 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("MIMC3_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0                         # rehearsal only: every rank shares GPU 0 (gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # ---- inputs (seeded; identical images on every rank) -------------------------------------
     case = synth.make_case(args.config)
     H, W = case.i0.shape
+    from mimc3_amd import shard
     xy = case.xyuvav.copy()
-    if rank:                                   # rank r's lattice: shifted r px in x
-        xy[:, 2] += rank
-        xy[:, 0] += rank * case.mpp
+    n_job = xy.shape[0] * (world if args.scaling == "weak" else 1)   # grid points of the whole job per step
+    if args.scaling == "weak":
+        if rank:                               # rank r's lattice: shifted r px in x
+            xy[:, 2] += rank
+            xy[:, 0] += rank * case.mpp
+        per = xy.shape[0]
+    else:
+        lo, hi, per = shard.block_range(xy.shape[0], world, rank)
+        xy = np.ascontiguousarray(xy[lo:hi])
     n = xy.shape[0]
     piv_off, piv_uv = api.get_uv_pivot(xy, case.dt, case.mpp, case.ocw, H, W)
     extent = api.pivot_extent(piv_off, piv_uv)
@@ -90,8 +107,8 @@ def main():
     d_xy = torch.from_numpy(xy).to(dev)
     d_uv = torch.from_numpy(piv_uv).to(dev)
     d_off = torch.from_numpy(piv_off).to(dev)
-    d_out = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    d_all = torch.empty((world * n, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    d_out = torch.full((per, 3), float("nan"), dtype=torch.float32, device=dev)   # padded to the block size
+    d_all = torch.empty((world * per, 3), dtype=torch.float32, device=dev) if world > 1 else None
 
     ctx = api.Context(local_rank)
     t_prep0 = time.perf_counter()
@@ -108,7 +125,10 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI: the one exchange step
+            else:
+                dist.all_gather(list(d_all.view(world, per, 3).unbind(0)), d_out)
 
     for _ in range(args.warmup):
         step()
@@ -130,18 +150,18 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     if rank == 0:
-        total_pts = world * n * args.steps
+        total_pts = n_job * args.steps
         value = total_pts / elapsed
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "grid-points/s (DLC NCC match)", "value": value, "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": ("u8 pixels, exact u32 dot4 sums, f64 NCC" if ctx.last_path() == "u8_exact"
                       else "f32 pixels, f32 products, f64 sums and NCC"),
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points per GPU "
+            "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points on rank 0 of {n_job} per step "
                                    f"({case.dimx}x{case.dimy}), ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), "
                                    f"{extent[0]} pivots max, window up to {2 * (extent[1] + case.ocw + 2) + 1}^2",
                        "grid_points_per_gpu": n, "image": [H, W], "ocw": case.ocw,
@@ -152,7 +172,7 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
         }
-        got = d_out.cpu().numpy()
+        got = d_out[:n].cpu().numpy()
         valid = got[:, 2] > -2.5
         res["check"] = {"valid_frac": float(valid.mean()),
                         "median_du_dv": [float(np.nanmedian(got[:, 0])), float(np.nanmedian(got[:, 1]))],

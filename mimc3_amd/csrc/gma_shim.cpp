@@ -1,0 +1,163 @@
+// gma_shim.cpp -- the reference's four hot-path entry points (exact names/signatures) over the
+// flat C ABI of libmimc3_hip.so.  See include/mimc3_gma_shim.h.  Host-only translation unit.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/mimc3_hip.h"
+#include "../../include/mimc3_gma_shim.h"
+
+// process globals owned by the reference's main() (MIMC_main.c:38-41)
+extern "C" {
+extern int32_t dimx_vmap, dimy_vmap, num_grid;
+extern param param_mimc2;
+}
+
+namespace {
+
+mimc3_ctx *g_ctx = nullptr;
+
+[[noreturn]] void die(const char *where, int rc)
+{
+    std::fprintf(stderr, "mimc3 shim: %s failed (rc=%d): %s\n", where, rc, mimc3_last_error());
+    std::abort();
+}
+
+mimc3_ctx *ctx()
+{
+    if (!g_ctx) {
+        const char *dev = std::getenv("MIMC3_DEVICE");
+        int rc = mimc3_ctx_create(dev ? std::atoi(dev) : 0, &g_ctx);
+        if (rc) die("mimc3_ctx_create", rc);
+    }
+    return g_ctx;
+}
+
+template <class G, class T>
+G *gma_create(int32_t nrows, int32_t ncols)   // same three malloc blocks as GMA_*_create (GMA.c:54-102)
+{
+    G *g = static_cast<G *>(std::malloc(sizeof(G)));
+    g->nrows = nrows; g->ncols = ncols;
+    g->val = static_cast<T **>(std::malloc(sizeof(T *) * (size_t)(nrows > 0 ? nrows : 1)));
+    g->data = static_cast<T *>(std::malloc(sizeof(T) * (size_t)(nrows > 0 ? nrows : 1) * (size_t)(ncols > 0 ? ncols : 1)));
+    for (int32_t r = 0; r < nrows; ++r) g->val[r] = g->data + (size_t)r * ncols;
+    return g;
+}
+
+// the reference addresses arrays through val[r][c]; rows are contiguous in `data` for every array
+// created by GMA_*_create, but be safe and gather through val[] when data is not the row base
+template <class G, class T>
+const T *flat(const G *g, std::vector<T> &tmp)
+{
+    bool contiguous = g->data != nullptr;
+    for (int32_t r = 0; contiguous && r < g->nrows; ++r) contiguous = (g->val[r] == g->data + (size_t)r * g->ncols);
+    if (contiguous) return g->data;
+    tmp.resize((size_t)g->nrows * g->ncols);
+    for (int32_t r = 0; r < g->nrows; ++r) std::memcpy(tmp.data() + (size_t)r * g->ncols, g->val[r], sizeof(T) * g->ncols);
+    return tmp.data();
+}
+
+}  // namespace
+
+extern "C" void mimc3_gma_shim_shutdown(void)
+{
+    if (g_ctx) mimc3_ctx_destroy(g_ctx);
+    g_ctx = nullptr;
+}
+
+extern "C" GMA_int32 **get_uv_pivot(GMA_double *xyuvav, float dt, param p, int32_t ocw, GMA_float *i1)
+{
+    const int32_t N = xyuvav->nrows;
+    std::vector<double> tmp;
+    const double *xy = flat<GMA_double, double>(xyuvav, tmp);
+    std::vector<int64_t> off((size_t)N + 1);
+    int64_t total = 0;
+    int rc = mimc3_get_uv_pivot(xy, N, dt, p.mpp, p.AW_SF, p.AW_CRE, ocw, i1->nrows, i1->ncols, off.data(), nullptr, 0, &total);
+    if (rc) die("mimc3_get_uv_pivot", rc);
+    std::vector<int32_t> uv(2 * (size_t)total);
+    rc = mimc3_get_uv_pivot(xy, N, dt, p.mpp, p.AW_SF, p.AW_CRE, ocw, i1->nrows, i1->ncols, off.data(), uv.data(), total, &total);
+    if (rc) die("mimc3_get_uv_pivot", rc);
+    GMA_int32 **out = static_cast<GMA_int32 **>(std::malloc(sizeof(GMA_int32 *) * (size_t)N));
+    for (int32_t g = 0; g < N; ++g) {
+        const int32_t n = (int32_t)(off[g + 1] - off[g]);
+        out[g] = gma_create<GMA_int32, int32_t>(n, 2);
+        std::memcpy(out[g]->data, uv.data() + 2 * off[g], sizeof(int32_t) * 2 * (size_t)n);
+    }
+    std::printf("\n");   // the reference prints a newline here (MIMC_module.c:600)
+    return out;
+}
+
+extern "C" GMA_float *matching_ncc_dlc_2(GMA_float *i0, GMA_float *i1, GMA_double *xyuvav, int32_t *offset,
+                                         GMA_int32 **uv_pivot, int32_t ocw, float, float)
+{
+    const int32_t N = xyuvav->nrows;
+    std::vector<float> t0, t1;
+    std::vector<double> txy;
+    // The CLI rewrites its filtered image buffers in place between passes (MIMC_main.c:309-310), so
+    // pointer identity says nothing about content: upload on every call (2 x H x W x 4 bytes).
+    int rc = mimc3_ctx_set_images(ctx(), flat<GMA_float, float>(i0, t0), flat<GMA_float, float>(i1, t1), i0->nrows, i0->ncols);
+    if (rc) die("mimc3_ctx_set_images", rc);
+    std::vector<int64_t> off((size_t)N + 1, 0);
+    for (int32_t g = 0; g < N; ++g) off[g + 1] = off[g] + uv_pivot[g]->nrows;
+    std::vector<int32_t> uv(2 * (size_t)off[N]);
+    for (int32_t g = 0; g < N; ++g)
+        for (int32_t k = 0; k < uv_pivot[g]->nrows; ++k) {
+            uv[2 * (off[g] + k)] = uv_pivot[g]->val[k][0];
+            uv[2 * (off[g] + k) + 1] = uv_pivot[g]->val[k][1];
+        }
+    GMA_float *out = gma_create<GMA_float, float>(N, 3);
+    rc = mimc3_match_ncc_dlc(ctx(), flat<GMA_double, double>(xyuvav, txy), N, offset, uv.data(), off.data(), ocw, 0, out->data);
+    if (rc) die("mimc3_match_ncc_dlc", rc);
+    return out;
+}
+
+extern "C" GMA_int32 *get_ruv_neighbor(GMA_double *xyuvav, float radius_neighbor)
+{
+    std::vector<double> txy;
+    const int32_t cap = 16384;
+    std::vector<int32_t> ruv(2 * (size_t)cap);
+    int32_t nn = 0;
+    int rc = mimc3_get_ruv_neighbor(flat<GMA_double, double>(xyuvav, txy), xyuvav->nrows, dimx_vmap, dimy_vmap,
+                                    param_mimc2.meter_per_spacing, radius_neighbor, ruv.data(), cap, &nn);
+    if (rc) die("mimc3_get_ruv_neighbor", rc);
+    GMA_int32 *out = gma_create<GMA_int32, int32_t>(nn, 2);
+    std::memcpy(out->data, ruv.data(), sizeof(int32_t) * 2 * (size_t)nn);
+    return out;
+}
+
+extern "C" void get_dpf_pseudosmoothing(GMA_int32 *dpf, GMA_float *dpf_dx, GMA_float *dpf_dy, GMA_int32 *ruv_neighbor,
+                                        GMA_float **mvn_dp, GMA_double *xyuvav)
+{
+    const int32_t dimx = dimx_vmap, dimy = dimy_vmap, N = dimx * dimy;
+    int32_t kmax = 1;
+    for (int32_t g = 0; g < N; ++g) if (mvn_dp[g]->nrows > kmax) kmax = mvn_dp[g]->nrows;
+    std::vector<float> mvn((size_t)N * kmax * 5, 0.0f);
+    std::vector<int32_t> nclus((size_t)N);
+    for (int32_t g = 0; g < N; ++g) {
+        nclus[g] = mvn_dp[g]->nrows;
+        for (int32_t c = 0; c < mvn_dp[g]->nrows; ++c)
+            std::memcpy(mvn.data() + ((size_t)g * kmax + c) * 5, mvn_dp[g]->val[c], sizeof(float) * 5);
+    }
+    std::vector<int32_t> tr, td;
+    std::vector<float> tx, ty;
+    std::vector<double> txy;
+    // in-place contract: work on contiguous copies when the caller's rows are not contiguous
+    const int32_t *ruv = flat<GMA_int32, int32_t>(ruv_neighbor, tr);
+    std::vector<int32_t> d((size_t)N);
+    std::vector<float> x((size_t)N), y((size_t)N);
+    for (int32_t r = 0; r < dimy; ++r) {
+        std::memcpy(d.data() + (size_t)r * dimx, dpf->val[r], sizeof(int32_t) * dimx);
+        std::memcpy(x.data() + (size_t)r * dimx, dpf_dx->val[r], sizeof(float) * dimx);
+        std::memcpy(y.data() + (size_t)r * dimx, dpf_dy->val[r], sizeof(float) * dimx);
+    }
+    int32_t sweeps = 0;
+    int rc = mimc3_qm_pseudosmooth(ctx(), dimy, dimx, d.data(), x.data(), y.data(), ruv, ruv_neighbor->nrows, mvn.data(), kmax,
+                                   nclus.data(), flat<GMA_double, double>(xyuvav, txy), 101 /* NOI<=100, :2077 */, &sweeps);
+    if (rc) die("mimc3_qm_pseudosmooth", rc);
+    for (int32_t r = 0; r < dimy; ++r) {
+        std::memcpy(dpf->val[r], d.data() + (size_t)r * dimx, sizeof(int32_t) * dimx);
+        std::memcpy(dpf_dx->val[r], x.data() + (size_t)r * dimx, sizeof(float) * dimx);
+        std::memcpy(dpf_dy->val[r], y.data() + (size_t)r * dimx, sizeof(float) * dimx);
+    }
+    std::printf("pseudosmoothing on device: NOI=%d\n", sweeps);
+}
