@@ -38,7 +38,9 @@ struct MatchU8Args {
     int32_t ocw, swap;
     float *out;
     // LDS carve, filled by the launcher
-    int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv;
+    int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
+    unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
+    int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off
 };
 
 // f32 image -> zero-bordered u8 plane (plane must be pre-zeroed); *d_flag is set to 1 if any pixel

@@ -23,6 +23,8 @@
 //     the cached NCC values, exactly as in match_kernel.hip (first-wins arg-max, observable laziness).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
 #include "match_kernel.h"
 
 namespace mimc3 {
@@ -55,6 +57,20 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return v;
 }
 
+// first-wins arg-max over the 16 lanes of a DPP row (lexicographic max on (value, -index)); VALU only
+__device__ __forceinline__ void argmax_row16(float &v, int &i)
+{
+#define MIMC3_ARGMAX_STEP(ctrl)                                                                           \
+    {                                                                                                     \
+        const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, i, ctrl, 0xF, 0xF, true);                           \
+        const bool t = (ov > v) || (ov == v && oi < i);                                                   \
+        v = t ? ov : v; i = t ? oi : i;                                                                   \
+    }
+    MIMC3_ARGMAX_STEP(0xB1) MIMC3_ARGMAX_STEP(0x4E) MIMC3_ARGMAX_STEP(0x141) MIMC3_ARGMAX_STEP(0x140)
+#undef MIMC3_ARGMAX_STEP
+}
+
 template <int OCW_, int LPC_>
 struct U8Cfg {
     static constexpr int OCW = OCW_, LPC = LPC_;
@@ -73,19 +89,31 @@ struct U8Point {
     int dx2, dy2, Dx2, Dy2, csx, csy, ncell;
     int sh;            // byte phase of window column 0 inside its aligned dword
     int PW;            // LDS window pitch, bytes
-    uint32_t SX, SXX;  // chip constants (FAST mode)
-    bool fast;
+    uint32_t NV, SX, SXX;   // chip constants: valid pixels, sum a, sum a^2 (nulls are 0 so they drop out)
 };
 
-// accumulators of one evaluation round (per lane, before the group reduction)
+// Evaluation modes, chosen PER CELL (the 64/LPC cells of a round share one mode):
+//   FAST     chip has no null and the cell's box of the window has no null : n, sx, sxx constant
+//   CHIPNULL chip has nulls, box has none                                    : n, sx, sxx constant
+//   GENERAL  the box contains null window pixels                             : all six sums
+enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2 };
+
 struct Acc { uint32_t n, sx, sy, sxx, syy, sxy; };
 
-template <class C, bool FAST>
-__device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t mf, uint32_t pad01, uint32_t padff, uint32_t bw)
+template <int MODE>
+__device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t mf, uint32_t pad01, uint32_t padff, bool static_pad,
+                                     uint32_t bw)
 {
-    if (FAST) {   // chip and window free of nulls: mf == padff, n/sx/sxx are per-point constants
-        acc.sy = dot4(pad01, bw, acc.sy);
-        acc.syy = dot4(padff == 0xffffffffu ? bw : (bw & padff), bw, acc.syy);
+    if (MODE == M_FAST) {
+        // mf is exactly the pad mask here; for the unrolled full rows it is a compile-time constant
+        const uint32_t m01 = static_pad ? pad01 : (mf & 0x01010101u);
+        const uint32_t mff = static_pad ? padff : mf;
+        acc.sy = dot4(m01, bw, acc.sy);
+        acc.syy = dot4((static_pad && padff == 0xffffffffu) ? bw : (bw & mff), bw, acc.syy);
+        acc.sxy = dot4(a, bw, acc.sxy);
+    } else if (MODE == M_CHIPNULL) {
+        acc.sy = dot4(mf & 0x01010101u, bw, acc.sy);
+        acc.syy = dot4(bw & mf, bw, acc.syy);
         acc.sxy = dot4(a, bw, acc.sxy);
     } else {
         const uint32_t t = nz80(bw);
@@ -102,7 +130,7 @@ __device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t mf, uint32_t
 
 // One evaluation round: lane group g (LPC lanes) evaluates the cell whose chip origin in window
 // coordinates is (cx, cy) (== compact cell coordinates).  Returns group-reduced sums in every lane.
-template <class C, bool FAST>
+template <class C, int MODE>
 __device__ __forceinline__ Acc eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&MF)[C::RF > 0 ? C::RF : 1][C::GPR],
@@ -125,25 +153,17 @@ __device__ __forceinline__ Acc eval_round(const unsigned char *W, const U8Point 
             const uint32_t bw = alignb(w[j + 1], w[j], s);
             const uint32_t p01 = (j == C::GPR - 1) ? C::LAST01 : 0x01010101u;
             const uint32_t pff = (j == C::GPR - 1) ? C::LASTFF : 0xffffffffu;
-            task<C, FAST>(acc, A[i][j], MF[i][j], p01, pff, bw);
+            task<MODE>(acc, A[i][j], MF[i][j], p01, pff, true, bw);
         }
     }
 #pragma unroll
     for (int k = 0; k < C::TT; k++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + toff[k]);
         const uint32_t bw = alignb(rp[1], rp[0], s);
-        // tail tasks carry their pad/null masks in MFT (zero for unused slots): use the general
-        // byte-mask form of the FAST sums so one code path serves every lane
-        if (FAST) {
-            acc.sy = dot4(MFT[k] & 0x01010101u, bw, acc.sy);
-            acc.syy = dot4(bw & MFT[k], bw, acc.syy);
-            acc.sxy = dot4(AT[k], bw, acc.sxy);
-        } else {
-            task<C, false>(acc, AT[k], MFT[k], 0, 0, bw);
-        }
+        task<MODE>(acc, AT[k], MFT[k], 0, 0, false, bw);   // tail tasks carry their pad/null masks in MFT
     }
     acc.sy = group_sum<C::LPC>(acc.sy); acc.syy = group_sum<C::LPC>(acc.syy); acc.sxy = group_sum<C::LPC>(acc.sxy);
-    if (!FAST) {
+    if (MODE == M_GENERAL) {
         acc.n = group_sum<C::LPC>(acc.n); acc.sx = group_sum<C::LPC>(acc.sx); acc.sxx = group_sum<C::LPC>(acc.sxx);
     }
     return acc;
@@ -158,9 +178,19 @@ __device__ __forceinline__ float ncc_from_sums(uint32_t n, uint32_t sx, uint32_t
     return (float)(num / den);
 }
 
+static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in LDS before the f64 finish
+
+#define MIMC3_STAMP(i)                                                                         \
+    if (p.stats) {                                                                             \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
+        if (lane == 0) p.stats[8 * (size_t)blockIdx.x + i] += t_now - t_prev;                   \
+        t_prev = t_now;                                                                        \
+    }
+
 template <class C>
 __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 {
+    unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int l = lane & (C::LPC - 1), grp = lane / C::LPC;
@@ -199,17 +229,20 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
-    float *val = reinterpret_cast<float *>(smem + p.lds_off_val);         // [csy][csx]
-    unsigned char *vis = smem + p.lds_off_vis;                            // [csy][csx]
-    uint16_t *list = reinterpret_cast<uint16_t *>(smem + p.lds_off_list); // certain-set cell ids
-    uint32_t *sums = reinterpret_cast<uint32_t *>(smem + p.lds_off_sums); // [64][6]
+    float *val = reinterpret_cast<float *>(smem + p.lds_off_val);         // [csy][csx] NCC cache
+    uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits
+    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // packed cells (cy<<16|cx): clean boxes from the front, dirty from the back
+    uint32_t *sums = reinterpret_cast<uint32_t *>(smem + p.lds_off_sums); // [kSumBatch][6]
     int32_t *pivs = reinterpret_cast<int32_t *>(smem + p.lds_off_piv);    // [npiv][2]
+    const int lcap = p.lds_list_cap;
 
-    for (int i = lane; i < pt.ncell; i += 64) { val[i] = kUnknown; vis[i] = 0; }
+    for (int i = lane; i < pt.ncell; i += 64) val[i] = kUnknown;
+    for (int i = lane; i < ((pt.ncell + 31) >> 5); i += 64) vis[i] = 0u;
     for (int i = lane; i < 2 * npiv; i += 64) pivs[i] = pv_g[i];
 
-    // ---- stage the window as aligned dwords; count null bytes on the way (a5, a6) ---------------
+    // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
     int bad_win = 0;
+    int nbx0 = 1 << 20, nbx1 = -1, nby0 = 1 << 20, nby1 = -1;   // bounding box of null pixels (window coords, dword-granular in x)
     {
         const int wcols = 2 * pt.dx2, wrows = 2 * pt.dy2;                 // written area (:869-886)
         const int nd = (pt.sh + wcols + 3) >> 2;                          // aligned dwords per row
@@ -229,16 +262,30 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             if (c == nd - 1) keep &= last_ff;
             v &= keep;                                                    // bytes outside the written columns -> 0 (covers T4 column)
             *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = v;
-            bad_win += __popc(keep & 0x01010101u) - __popc((nz80(v) >> 7));
+            const int nz = __popc(keep & 0x01010101u) - __popc((nz80(v) >> 7));
+            bad_win += nz;
+            if (nz) {
+                const int x0 = 4 * c - pt.sh;
+                nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + 3); nby0 = min(nby0, r); nby1 = max(nby1, r);
+            }
         }
-        // T4: the last window row is never written by the reference -> zeros; also clear the dword
+        // T4: the last window row is never written by the reference -> zeros; also clear the dwords
         // after each row's last written dword (read by the sliding loads of the right-most cells)
         const int ndz = pt.PW >> 2;
         for (int c = lane; c < ndz; c += 64) *reinterpret_cast<uint32_t *>(W + wrows * pt.PW + 4 * c) = 0u;
         for (int r = lane; r < wrows; r += 64)
             for (int c = nd; c < ndz; c++) *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = 0u;
-        bad_win = wave_sum_i(bad_win) + pt.Dx2 + pt.Dy2 - 1;              // + the never-written last row and column
+        bad_win = wave_sum_i(bad_win);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nbx0 = min(nbx0, __shfl_xor(nbx0, o, 64)); nbx1 = max(nbx1, __shfl_xor(nbx1, o, 64));
+            nby0 = min(nby0, __shfl_xor(nby0, o, 64)); nby1 = max(nby1, __shfl_xor(nby1, o, 64));
+        }
     }
+    if (p.debug_stop == 1) return;
+    MIMC3_STAMP(0)
+    const bool win_clean = (bad_win == 0);                   // no null inside the written area
+    bad_win += pt.Dx2 + pt.Dy2 - 1;                          // + the never-written last row and column
 
     // ---- chip -> registers (a4): every lane group holds the whole chip --------------------------
     constexpr int RFA = C::RF > 0 ? C::RF : 1, TTA = C::TT > 0 ? C::TT : 1;
@@ -290,7 +337,10 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
         bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip);
         SX = group_sum<C::LPC>(SX); SXX = group_sum<C::LPC>(SXX);
     }
-    pt.SX = SX; pt.SXX = SXX;
+    pt.SX = SX; pt.SXX = SXX; pt.NV = (uint32_t)(C::NPX - bad_chip);
+    const int clean_mode = (bad_chip == 0) ? M_FAST : M_CHIPNULL;
+    MIMC3_STAMP(1)
+    if (p.debug_stop == 2) { if (lane == 0) p.out[3 * (size_t)gidx] = (float)(SX + SXX + bad_chip + A[0][0] + AT[0]); return; }
     __syncthreads();   // single-wave workgroup: orders the LDS stores above before the reads below
 
     // ---- validity (a6, :635) --------------------------------------------------------------------
@@ -308,49 +358,64 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             return;
         }
     }
-    pt.fast = (bad_chip == 0) && (bad_win == pt.Dx2 + pt.Dy2 - 1);
     if (OCW == 1)   // T4 cmap cells (only reachable by the fit when ocw == 1)
         for (int i = lane; i < pt.ncell; i += 64) {
             const int cy = i / pt.csx, cx = i - cy * pt.csx;
-            if (cx + OCW == pt.Dx2 - 1 || cy + OCW == pt.Dy2 - 1) { val[i] = 0.0f; vis[i] = 1; }
+            if (cx + OCW == pt.Dx2 - 1 || cy + OCW == pt.Dy2 - 1) { val[i] = 0.0f; atomicOr(&vis[i >> 5], 1u << (i & 31)); }
         }
 
-    // ---- certain set: 3x3 around every pivot start that passes the boundary test ----------------
+    // a cell's 33x33 (CW x CW) box of the window is null-free iff it avoids the null bounding box and
+    // the zero last row/column (T4)
+    auto box_clean = [&](int cx, int cy) __attribute__((always_inline)) -> bool {
+        if (cx == pt.csx - 2 || cy == pt.csy - 2) return false;
+        if (win_clean) return true;
+        return (cx > nbx1) || (cx + CW - 1 < nbx0) || (cy > nby1) || (cy + CW - 1 < nby0);
+    };
+
+    // ---- request queue: a cell is requested at most once (CAS on its cache slot); clean boxes are
+    //      queued from the front of `list`, dirty boxes from the back ------------------------------
+    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // [0] clean count, [1] dirty count
+    if (lane < 2) qcnt[lane] = 0;
+    __syncthreads();
+    auto request = [&](int cx, int cy) __attribute__((always_inline)) {
+        int *slot = reinterpret_cast<int *>(&val[cy * pt.csx + cx]);
+        if (atomicCAS(slot, __float_as_int(kUnknown), __float_as_int(kWanted)) != __float_as_int(kUnknown)) return;
+        const uint32_t packed = ((uint32_t)cy << 16) | (uint32_t)cx;
+        if (box_clean(cx, cy)) list[atomicAdd(&qcnt[0], 1)] = packed;
+        else list[lcap - 1 - atomicAdd(&qcnt[1], 1)] = packed;
+    };
+    auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
+        return !(pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1);
+    };
+    // round 0 = the certain set: every pivot whose start passes the boundary test scans its whole 3x3
     for (int k = lane; k < npiv; k += 64) {
         const int pu = pivs[2 * k] + pt.dx2, pvv = pivs[2 * k + 1] + pt.dy2;
-        if (pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1) continue;
+        if (!inside(pu, pvv)) continue;
 #pragma unroll
-        for (int j = 0; j < 9; j++) val[(pvv + (j % 3 - 1) - OCW) * pt.csx + (pu + (j / 3 - 1) - OCW)] = kWanted;
+        for (int j = 0; j < 9; j++) request(pu + (j / 3 - 1) - OCW, pvv + (j % 3 - 1) - OCW);
     }
     __syncthreads();
-    int nlist = 0;
-    for (int base = 0; base < pt.ncell; base += 64) {
-        const int cell = base + lane;
-        const bool want = (cell < pt.ncell) && (val[cell] == kWanted);
-        const unsigned long long m = __ballot(want);
-        if (want) list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)cell;
-        nlist += __popcll(m);
-    }
-    __syncthreads();
+    if (p.debug_stop == 3) return;
+    MIMC3_STAMP(2)
 
-    // evaluates `cnt` cells whose ids are ids[0..cnt) (LDS) and stores their NCC into val[]
-    auto evaluate = [&](const uint16_t *ids, int cnt) {
-        for (int b0 = 0; b0 < cnt; b0 += 64) {
-            const int nb = (cnt - b0) < 64 ? (cnt - b0) : 64;
+    // evaluates the `cnt` cells ids[0], ids[dir], ids[2*dir], ... in mode `mode`; NCC -> val[]
+    auto evaluate = [&](const uint32_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
+        for (int b0 = 0; b0 < cnt; b0 += kSumBatch) {
+            const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
             for (int r0 = 0; r0 < nb; r0 += C::CPR) {
                 const int slot = r0 + grp;
                 const bool on = slot < nb;
-                const int cell = on ? (int)ids[b0 + slot] : 0;
-                const int cy = cell / pt.csx, cx = cell - cy * pt.csx;
-                // FAST needs a null-free box: cells touching the zero last row/column (T4) do not qualify
-                const bool edge = on && (cx == pt.csx - 2 || cy == pt.csy - 2);
+                const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00010001u;
+                const int cx = (int)(pk & 0xffffu), cy = (int)(pk >> 16);
                 Acc acc;
-                if (pt.fast && !__any(edge)) {
-                    acc = eval_round<C, true>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
-                    acc.n = C::NPX; acc.sx = pt.SX; acc.sxx = pt.SXX;
+                if (mode == M_FAST) {
+                    acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
+                } else if (mode == M_CHIPNULL) {
+                    acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
                 } else {
-                    acc = eval_round<C, false>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
+                    acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
                 }
+                if (mode != M_GENERAL) { acc.n = pt.NV; acc.sx = pt.SX; acc.sxx = pt.SXX; }
                 if (on && l == 0) {
                     uint32_t *sp = sums + 6 * slot;
                     sp[0] = acc.n; sp[1] = acc.sx; sp[2] = acc.sy; sp[3] = acc.sxx; sp[4] = acc.syy; sp[5] = acc.sxy;
@@ -359,67 +424,221 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             __syncthreads();
             if (lane < nb) {
                 const uint32_t *sp = sums + 6 * lane;
-                val[ids[b0 + lane]] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
+                const uint32_t pk = ids[dir * (b0 + lane)];
+                val[(int)(pk >> 16) * pt.csx + (int)(pk & 0xffffu)] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
             }
             __syncthreads();
         }
     };
-    evaluate(list, nlist);
-
-    // ---- hill climb (resumable) + on-demand evaluation -----------------------------------------
+    // ---- driver loop: [evaluate everything queued] -> [speculative climb step | exact state machine] ----
+    // Speculative parallel climb (stages 0..kSpecRounds-1): lane k follows pivot k's hill climb on the
+    // cached values, ignoring the visited state (which can only END a real climb earlier), so that the
+    // cells the sequential state machine will ask for are evaluated in a few bulk batches.  Purely a
+    // prefetch: it never touches `vis`; the result is decided by the exact replay (stage kSpecRounds).
+    constexpr int kSpecRounds = 10;
+    int stage = 0;
+    int su = 0, sv = 0;
+    bool alive = false;
+    float smax = -2.0f;
+    if (lane < npiv) {
+        su = pivs[2 * lane] + pt.dx2; sv = pivs[2 * lane + 1] + pt.dy2;
+        alive = inside(su, sv);
+    }
+    const int start_u = su, start_v = sv;            // lane k keeps pivot k's start for the replay (k < 64)
+    // lane k's speculative trajectory: position before scan t, running max after scan t, which scans moved
+    uint32_t posr[kSpecRounds + 1];
+    float smr[kSpecRounds];
+    uint32_t movedmask = 0;
+    int nscan = 0;
+#pragma unroll
+    for (int t = 0; t <= kSpecRounds; t++) posr[t] = ((uint32_t)sv << 16) | (uint32_t)su;
+#pragma unroll
+    for (int t = 0; t < kSpecRounds; t++) smr[t] = -2.0f;
+    bool replay_generic = false;
+    // wave-uniform state of the reference's loops (:691-753)
     int k = 0, pu = 0, pvv = 0, du = 0, dv = 0, newncc = 0;
     bool fresh = true;
     float nccmax = -2.0f, best = -2.0f;
     int peak_u = pt.dx2, peak_v = pt.dy2;
-    for (int guard = 0; guard <= pt.ncell + 8; guard++) {
-        int npend = 0;
+
+    for (int guard = 0; guard <= pt.ncell + 16; guard++) {
+        {   // evaluate everything queued, then empty the queue (the only call site of `evaluate`)
+            const int nA = qcnt[0], nB = qcnt[1];
+            __syncthreads();
+            if (lane < 2) qcnt[lane] = 0;
+            evaluate(list, 1, nA, clean_mode);
+            evaluate(list + lcap - 1, -1, nB, M_GENERAL);
+            __syncthreads();
+        }
+        if (p.debug_stop == 4) return;
+        MIMC3_STAMP(3)
+        if (stage < kSpecRounds) {
+            if (alive) {
+                int mv = -1;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const float v = val[(sv + (j % 3 - 1) - OCW) * pt.csx + (su + (j / 3 - 1) - OCW)];
+                    if (v > smax && v < 2.5f) { smax = v; mv = j; }   // NaN never wins; unknown sentinels (>= 3) ignored
+                }
+                const bool moved = (mv >= 0 && mv != 4);
+                if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; movedmask |= 1u << stage; }
+                nscan = stage + 1;
+#pragma unroll
+                for (int t = 0; t < kSpecRounds; t++)
+                    if (stage == t) { smr[t] = smax; posr[t + 1] = ((uint32_t)sv << 16) | (uint32_t)su; }
+                alive = moved && inside(su, sv);
+                if (alive) {
+#pragma unroll
+                    for (int j = 0; j < 9; j++) request(su + (j / 3 - 1) - OCW, sv + (j % 3 - 1) - OCW);
+                }
+            }
+            __syncthreads();
+            stage++;
+            MIMC3_STAMP(4)
+            if (__any(alive) && stage < kSpecRounds) continue;   // next speculative scan (after evaluating its requests)
+            replay_generic = (npiv > 64) || __any(alive);          // a climb longer than kSpecRounds: exact generic replay
+            stage = kSpecRounds;
+            if (qcnt[0] + qcnt[1] != 0) continue;                  // (generic case) evaluate what was queued first
+        }
+        if (p.debug_stop == 5) return;
+        if (!replay_generic) {
+            // ---- exact replay from the recorded trajectories.  Every scan's move and running maximum
+            //      depend only on NCC values (identical to the reference's compare sequence, :736-741);
+            //      the visited state only decides HOW MANY scans of a pivot really happen (newncc != 0,
+            //      :699) -- that part is sequential over pivots and is all that is done here.
+            MIMC3_STAMP(5)
+            if (p.debug_stop == 8) return;
+            int T = 0;                                   // lane k: number of scans pivot k really performs
+            if (pt.csx <= 64 && pt.csy <= 64) {
+                // visited set in REGISTERS: lane r holds the 64-bit column mask of compact row r.  The 3x3
+                // of a scan is 3 rows x 3 adjacent bits, tested and set with readlane/writelane + scalar ops:
+                // no LDS round trip in this sequential chain.
+                uint32_t vlo = 0, vhi = 0;
+                for (int kk = 0; kk < npiv; kk++) {
+                    const int L = __builtin_amdgcn_readlane(nscan, kk);
+                    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)movedmask, kk);
+                    bool cont = true;
+                    int Tk = 0;
+#pragma unroll
+                    for (int t = 0; t < kSpecRounds; t++) {
+                        if (t < L && cont) {
+                            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)posr[t], kk);
+                            const int ccx = (int)(pk & 0xffffu) - OCW, ccy = (int)(pk >> 16) - OCW;
+                            const unsigned long long m3 = 7ull << (ccx - 1);
+                            int unv = 0;
+#pragma unroll
+                            for (int j = -1; j <= 1; j++) {
+                                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vhi, ccy + j) << 32) |
+                                                             (uint32_t)__builtin_amdgcn_readlane((int)vlo, ccy + j);
+                                unv += __builtin_popcountll(~m & m3);
+                                const unsigned long long mn = m | m3;
+                                const bool mine = (lane == ccy + j);
+                                vlo = mine ? (uint32_t)mn : vlo;
+                                vhi = mine ? (uint32_t)(mn >> 32) : vhi;
+                            }
+                            Tk = t + 1;
+                            cont = ((mm >> t) & 1u) && (unv != 0);
+                        }
+                    }
+                    if (lane == kk) T = Tk;
+                }
+                MIMC3_STAMP(6)
+                // publish the visited rows for the fit (bit array in LDS)
+                for (int c = 0; c < pt.csx; c++) {
+                    const bool on = (lane < pt.csy) && (((c < 32 ? vlo >> c : vhi >> (c - 32)) & 1u) != 0u);
+                    if (on) { const int cidx = lane * pt.csx + c; atomicOr(&vis[cidx >> 5], 1u << (cidx & 31)); }
+                }
+            } else {
+                const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
+                for (int kk = 0; kk < npiv; kk++) {
+                    const int L = __builtin_amdgcn_readlane(nscan, kk);
+                    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)movedmask, kk);
+                    bool cont = true;
+                    int Tk = 0;
+#pragma unroll
+                    for (int t = 0; t < kSpecRounds; t++) {
+                        if (t < L && cont) {
+                            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)posr[t], kk);
+                            const int cidx = (lane < 9) ? ((int)(pk >> 16) + c2 - OCW) * pt.csx + ((int)(pk & 0xffffu) + c1 - OCW) : 0;
+                            const bool unvis = (lane < 9) && (((vis[cidx >> 5] >> (cidx & 31)) & 1u) == 0u);
+                            const unsigned long long um = __ballot(unvis);
+                            if (unvis) atomicOr(&vis[cidx >> 5], 1u << (cidx & 31));
+                            Tk = t + 1;
+                            cont = ((mm >> t) & 1u) && (um != 0ull);
+                        }
+                    }
+                    if (lane == kk) T = Tk;
+                }
+            }
+            MIMC3_STAMP(7)
+            if (p.debug_stop == 7) { if (lane == 0) p.out[3 * (size_t)gidx] = (float)T; return; }
+            // lane k: where pivot k ended and with which maximum (:744-752)
+            uint32_t fpos = posr[0];
+            float fmax = -2.0f;
+#pragma unroll
+            for (int t = 0; t < kSpecRounds; t++)
+                if (T == t + 1) { fpos = posr[t + 1]; fmax = smr[t]; }
+            float bv = (lane < npiv) ? fmax : -__builtin_inff();
+            int bi = lane;
+            argmax_row16(bv, bi);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            bv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
+            bi = __builtin_amdgcn_readfirstlane(bi);
+            if (bv > -2.0f) {                            // strict >, first pivot attaining the maximum wins
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)fpos, bi);
+                peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
+            }
+            break;
+        }
+        // ---- exact hill climb (resumable), generic form: the reference's sequential loops ----------
         bool finished = false;
         for (;;) {
             if (fresh) {
                 if (k >= npiv) { finished = true; break; }
-                pu = pivs[2 * k] + pt.dx2; pvv = pivs[2 * k + 1] + pt.dy2;
+                if (k < 64) { pu = __builtin_amdgcn_readlane(start_u, k); pvv = __builtin_amdgcn_readlane(start_v, k); }
+                else { pu = pivs[2 * k] + pt.dx2; pvv = pivs[2 * k + 1] + pt.dy2; }
                 nccmax = -2.0f; du = -1; dv = -1; newncc = 1; fresh = false;
             }
             bool end_pivot = !((du != 0 || dv != 0) && newncc != 0);
-            if (!end_pivot && (pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1))
-                end_pivot = true;
+            if (!end_pivot && !inside(pu, pvv)) end_pivot = true;            // boundary break (:703-707)
             if (end_pivot) {
-                if (nccmax > best) { peak_u = pu; peak_v = pvv; best = nccmax; }
+                if (nccmax > best) { peak_u = pu; peak_v = pvv; best = nccmax; }   // :747-752
                 k++; fresh = true;
                 continue;
             }
             const bool act = lane < 9;
             const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
-            const int cidx = act ? (pvv + c2 - OCW) * pt.csx + (pu + c1 - OCW) : 0;
+            const int cx = pu + c1 - OCW, cy = pvv + c2 - OCW;
+            const int cidx = act ? cy * pt.csx + cx : 0;
             const float v = val[cidx];
-            const bool unvis = act && (vis[cidx] == 0);
+            const bool unvis = act && (((vis[cidx >> 5] >> (cidx & 31)) & 1u) == 0u);
             const bool missing = unvis && (v == kUnknown || v == kWanted);
-            const unsigned long long mm = __ballot(missing);
-            if (mm) {
-                if (missing) list[__popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)cidx;
-                npend = __popcll(mm);
+            if (__ballot(missing)) {
+                if (missing) { val[cidx] = kUnknown; request(cx, cy); }
                 break;
             }
             newncc = __popcll(__ballot(unvis));
-            if (unvis) vis[cidx] = 1;
+            if (unvis) atomicOr(&vis[cidx >> 5], 1u << (cidx & 31));
             float bv = (act && v == v) ? v : -__builtin_inff();
             int bi = lane;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            bv = __shfl(bv, 0, 64); bi = __shfl(bi, 0, 64);
+            argmax_row16(bv, bi);                       // lanes 0..15 now hold (max, first index attaining it)
+            bv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
+            bi = __builtin_amdgcn_readfirstlane(bi);
             du = 0; dv = 0;
             if (bv > nccmax) { nccmax = bv; du = bi / 3 - 1; dv = bi % 3 - 1; }
             pu += du; pvv += dv;
         }
         if (finished) break;
         __syncthreads();
-        evaluate(list, npend);
     }
 
+    MIMC3_STAMP(3)
+    if (p.debug_stop == 6) { if (lane == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
     // ---- 3x3 quadratic fit (:757-788) ----------------------------------------------------------
     if (lane == 0) {
         float n9[9];
@@ -428,7 +647,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const int cidx = (peak_v - 1 + r - OCW) * pt.csx + (peak_u - 1 + c - OCW);
-                n9[3 * r + c] = vis[cidx] ? val[cidx] : -2.0f;
+                n9[3 * r + c] = ((vis[cidx >> 5] >> (cidx & 31)) & 1u) ? val[cidx] : -2.0f;
             }
         double cp0, cp1, cp2, cp3, cp4;
         cp0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
@@ -448,6 +667,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
         p.out[3 * (size_t)gidx + 1] = o1;
         p.out[3 * (size_t)gidx + 2] = best;
     }
+    MIMC3_STAMP(3)
 }
 
 // ---- f32 image -> zero-bordered u8 plane, proving the image is 8-bit integral ---------------------
@@ -475,13 +695,16 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 {
     const int Dx2 = 2 * (max_abs_u + C::OCW + 2) + 1, Dy2 = 2 * (max_abs_v + C::OCW + 2) + 1;
     const int cells = (Dx2 - 2 * C::OCW + 1) * (Dy2 - 2 * C::OCW + 1);
-    // pitch: covering dwords of (phase 3 + Dx2 columns) + one zero dword + the sliding read-ahead
-    a.lds_pw = 4 * (((3 + Dx2 + 3) >> 2) + 2);
+    // pitch (dwords): written dwords + one zero dword, and the right-most cell's sliding read-ahead
+    const int csx = Dx2 - 2 * C::OCW + 1;
+    const int pw_a = ((3 + (Dx2 - 1) + 3) >> 2) + 1, pw_b = ((3 + csx - 2) >> 2) + C::GPR + 1;
+    a.lds_pw = 4 * (pw_a > pw_b ? pw_a : pw_b);
+    a.lds_list_cap = 9 * max_npiv + 16;
     size_t off = (size_t)a.lds_pw * Dy2;
     off = (off + 15) & ~(size_t)15; a.lds_off_val = (int)off; off += 4 * (size_t)cells;
-    off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += (size_t)cells;
-    off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 2 * (size_t)(9 * max_npiv + 16);
-    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * 64;
+    off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
+    off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
+    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 16;
     off = (off + 15) & ~(size_t)15; a.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
     off = (off + 15) & ~(size_t)15;
     if (off > 160 * 1024) return hipErrorInvalidValue;
@@ -492,7 +715,30 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
         attr_set = true;
     }
     const unsigned nb = (unsigned)((a.N + 7) & ~7);
+    static const int dbg = getenv("MIMC3_U8_DEBUG_STOP") ? atoi(getenv("MIMC3_U8_DEBUG_STOP")) : 0;
+    a.debug_stop = dbg;
+    static unsigned long long *d_stats = nullptr;
+    static const bool want_stats = getenv("MIMC3_U8_STATS") != nullptr;
+    static size_t stats_n = 0;
+    if (want_stats && stats_n < (size_t)nb) {
+        if (d_stats) (void)hipFree(d_stats);
+        (void)hipMalloc(&d_stats, 8 * sizeof(unsigned long long) * (size_t)nb);
+        stats_n = nb;
+    }
+    a.stats = want_stats ? d_stats : nullptr;
+    if (want_stats) (void)hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long) * (size_t)nb, stream);
     hipLaunchKernelGGL(match_ncc_dlc_u8<C>, dim3(nb), dim3(64), off, stream, a);
+    if (want_stats) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long *hh = (unsigned long long *)malloc(8 * sizeof(unsigned long long) * (size_t)nb);
+        (void)hipMemcpy(hh, d_stats, 8 * sizeof(unsigned long long) * (size_t)nb, hipMemcpyDeviceToHost);
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t b = 0; b < (size_t)nb; b++) for (int i = 0; i < 8; i++) h[i] += hh[8 * b + i];
+        free(hh);
+        fprintf(stderr, "[mimc3 u8 stats] cycles/point: stage %.0f chip %.0f request %.0f eval+fit %.0f spec %.0f pre-replay %.0f replay-loop %.0f publish %.0f\n",
+                (double)h[0] / a.N, (double)h[1] / a.N, (double)h[2] / a.N, (double)h[3] / a.N, (double)h[4] / a.N,
+                (double)h[5] / a.N, (double)h[6] / a.N, (double)h[7] / a.N);
+    }
     return hipGetLastError();
 }
 

@@ -70,11 +70,11 @@ def _blobs(img, frac, rng, radius=9):
         sub[disc] = 0.0
 
 
-def make_pair(h, w, shift, seed, subpixel=(0.0, 0.0), noise_dn=0, null_frac=0.0, bits=8, pad=64):
+def make_pair(h, w, shift, seed, subpixel=(0.0, 0.0), noise_dn=0, null_frac=0.0, bits=8, pad=64, sigma=2.0):
     """i1[v,u] = i0[v-dv, u-du]: a feature at (u,v) in i0 sits at (u+du, v+dv) in i1."""
     du, dv = int(shift[0]), int(shift[1])
     assert abs(du) < pad - 1 and abs(dv) < pad - 1
-    base = texture(h + 2 * pad, w + 2 * pad, seed, bits=bits)
+    base = texture(h + 2 * pad, w + 2 * pad, seed, sigma=sigma, bits=bits)
     i0 = base[pad:pad + h, pad:pad + w].copy()
     fu, fv = float(subpixel[0]), float(subpixel[1])
     if fu == 0.0 and fv == 0.0:

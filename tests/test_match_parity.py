@@ -106,6 +106,23 @@ def test_float_images_within_tolerance(api, oracle):
     assert np.nanmax(np.abs(got - want)) <= 1e-4
 
 
+@pytest.mark.parametrize("mode", ["auto", "general"])
+def test_long_climbs(api, oracle, mode):
+    """Smooth texture + a shift far along the corridor: pivots climb 10+ scans to the peak, which
+    exercises the u8 kernel's generic (sequential) replay behind the speculative one."""
+    c = synth.make_small(seed=91, shift=(13, -13), angle_deg=45.0, ocw=16, speed=6000.0, h=300, w=300, dimx=6, dimy=6,
+                         sigma=7.0, margin=70)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        ctx.set_path(mode)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+    assert_bits_equal(got, want)
+    assert np.abs(np.nanmedian(got[:, 0]) - 13) < 0.5
+
+
 def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
     """The CLI's schedule: ocw 7, 15, 30, 40 forward + swapped on one resident pair (MIMC_main.c:261-300)."""
     c = synth.make_small(seed=61, shift=(3, -3), angle_deg=45.0, ocw=40, speed=1200.0, h=330, w=340, dimx=5, dimy=5,
