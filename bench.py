@@ -52,6 +52,8 @@ def main():
                          "strong: the config's points are sharded across ranks (BASELINE configs[2])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default). gloo + MIMC3_BENCH_ONE_DEVICE=1 rehearses the N>1 path on a 1-GPU box")
+    ap.add_argument("--qm-sweeps", type=int, default=10,
+                    help="also time the QM pseudo-smoothing update (BASELINE configs[4]: 10 sweeps fused on device); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -179,10 +181,59 @@ def main():
                         "true_shift": list(case.shift)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = cpu_baseline(case, xy, piv_off, piv_uv, got, args.cpu_sample)
+        if args.qm_sweeps > 0:
+            res["qm"] = qm_leg(torch, api, synth, ctx, dev, case, args.qm_sweeps, check=(world == 1 and not args.no_cpu_baseline))
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def qm_leg(torch, api, synth, ctx, dev, case, sweeps, check, reps=5):
+    """Secondary figure (does not enter `value`): `sweeps` QM pseudo-smoothing sweeps on the config's
+    grid, all enqueued on the device without host synchronisation (get_dpf_pseudosmoothing,
+    MIMC_module.c:1986-2312), on synthetic candidate clusters; checked against the oracle."""
+    dimx, dimy = case.dimx, case.dimy
+    mvn, nclus, dpf, dx, dy = synth.synth_qm_state(dimx, dimy, seed=20260105)
+    xyg = case.xyuvav
+    mps = float(np.float32(xyg[1, 0] - xyg[0, 0]))
+    ruv = api.get_ruv_neighbor(xyg, dimx, dimy, mps, 5.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_mvn, d_ncl, d_xy, d_ruv = t(mvn), t(nclus), t(xyg), t(ruv)
+    src = (t(dpf), t(dx), t(dy))
+    wrk = (torch.empty_like(src[0]), torch.empty_like(src[1]), torch.empty_like(src[2]))
+    d_work = torch.empty(ctx.qm_workspace_bytes(dimx * dimy, sweeps), dtype=torch.uint8, device=dev)
+    d_sw = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    times = []
+    for _ in range(reps + 1):
+        for a, b in zip(wrk, src):
+            a.copy_(b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        ctx.get_dpf_pseudosmoothing_dev(dimy, dimx, wrk[0].data_ptr(), wrk[1].data_ptr(), wrk[2].data_ptr(), d_ruv.data_ptr(),
+                                        ruv.shape[0], d_mvn.data_ptr(), mvn.shape[1], d_ncl.data_ptr(), d_xy.data_ptr(), sweeps,
+                                        d_work.data_ptr(), d_sw.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = float(np.median(times[1:]))
+    out = {"sweeps_cap": sweeps, "sweeps_run": int(d_sw.item()), "grid": [dimy, dimx], "neighbours": int(ruv.shape[0]),
+           "ms": ms, "grid_points_per_s": dimx * dimy / (ms * 1e-3),
+           "investigated_frac_initial": float((mvn[np.arange(dimx * dimy), dpf.reshape(-1), 4] < 0.6).mean())}
+    if check:
+        from oracle import oracle as orc
+        o = orc.Oracle("port")
+        t0 = time.perf_counter()
+        wd, wx, wy, st = o.qm(dpf, dx, dy, ruv, mvn, nclus, xyg, max_sweeps=sweeps)
+        out["cpu_ms"] = (time.perf_counter() - t0) * 1e3
+        out["cpu_kind"] = "port (the reference's QM is serial too)"
+        gd, gx, gy = wrk[0].cpu().numpy(), wrk[1].cpu().numpy(), wrk[2].cpu().numpy()
+        out["identical"] = bool(np.array_equal(gd, wd) and np.array_equal(np.nan_to_num(gx).view(np.uint32), np.nan_to_num(wx).view(np.uint32))
+                                and np.array_equal(np.nan_to_num(gy).view(np.uint32), np.nan_to_num(wy).view(np.uint32)))
+        out["sweeps_cpu"] = int(st[0])
+        out["points_changed"] = int((gd != dpf).sum())
+    return out
 
 
 def cpu_baseline(case, xy, piv_off, piv_uv, gpu_out, sample):

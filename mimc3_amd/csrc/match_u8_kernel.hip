@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     const int lcap = p.lds_list_cap;
 
     for (int i = lane; i < pt.ncell; i += 64) val[i] = kUnknown;
-    for (int i = lane; i < ((pt.ncell + 31) >> 5); i += 64) vis[i] = 0u;
+    const int vpitch = ((pt.csx + 31) >> 5) << 5;          // visited bits: one row = whole 32-bit words
+    for (int i = lane; i < ((pt.csy * vpitch) >> 5); i += 64) vis[i] = 0u;
     for (int i = lane; i < 2 * npiv; i += 64) pivs[i] = pv_g[i];
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     if (OCW == 1)   // T4 cmap cells (only reachable by the fit when ocw == 1)
         for (int i = lane; i < pt.ncell; i += 64) {
             const int cy = i / pt.csx, cx = i - cy * pt.csx;
-            if (cx + OCW == pt.Dx2 - 1 || cy + OCW == pt.Dy2 - 1) { val[i] = 0.0f; atomicOr(&vis[i >> 5], 1u << (i & 31)); }
+            if (cx + OCW == pt.Dx2 - 1 || cy + OCW == pt.Dy2 - 1) { val[i] = 0.0f; const int vb = cy * vpitch + cx; atomicOr(&vis[vb >> 5], 1u << (vb & 31)); }
         }
 
     // a cell's 33x33 (CW x CW) box of the window is null-free iff it avoids the null bounding box and
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     // cached values, ignoring the visited state (which can only END a real climb earlier), so that the
     // cells the sequential state machine will ask for are evaluated in a few bulk batches.  Purely a
     // prefetch: it never touches `vis`; the result is decided by the exact replay (stage kSpecRounds).
-    constexpr int kSpecRounds = 10;
+    constexpr int kSpecRounds = 16;
     int stage = 0;
     int su = 0, sv = 0;
     bool alive = false;
@@ -445,15 +446,9 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
         alive = inside(su, sv);
     }
     const int start_u = su, start_v = sv;            // lane k keeps pivot k's start for the replay (k < 64)
-    // lane k's speculative trajectory: position before scan t, running max after scan t, which scans moved
-    uint32_t posr[kSpecRounds + 1];
-    float smr[kSpecRounds];
-    uint32_t movedmask = 0;
-    int nscan = 0;
-#pragma unroll
-    for (int t = 0; t <= kSpecRounds; t++) posr[t] = ((uint32_t)sv << 16) | (uint32_t)su;
-#pragma unroll
-    for (int t = 0; t < kSpecRounds; t++) smr[t] = -2.0f;
+    // lane k's speculative trajectory as 4-bit codes per scan: 0 = no scan, 1..9 = the scan updated the
+    // running maximum at 3x3 index code-1 (5 = centre: no move), 10 = scanned without update
+    unsigned long long traj = 0ull;
     bool replay_generic = false;
     // wave-uniform state of the reference's loops (:691-753)
     int k = 0, pu = 0, pvv = 0, du = 0, dv = 0, newncc = 0;
@@ -481,11 +476,8 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
                     if (v > smax && v < 2.5f) { smax = v; mv = j; }   // NaN never wins; unknown sentinels (>= 3) ignored
                 }
                 const bool moved = (mv >= 0 && mv != 4);
-                if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; movedmask |= 1u << stage; }
-                nscan = stage + 1;
-#pragma unroll
-                for (int t = 0; t < kSpecRounds; t++)
-                    if (stage == t) { smr[t] = smax; posr[t + 1] = ((uint32_t)sv << 16) | (uint32_t)su; }
+                if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; }
+                traj |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * stage);
                 alive = moved && inside(su, sv);
                 if (alive) {
 #pragma unroll
@@ -509,75 +501,63 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             MIMC3_STAMP(5)
             if (p.debug_stop == 8) return;
             int T = 0;                                   // lane k: number of scans pivot k really performs
-            if (pt.csx <= 64 && pt.csy <= 64) {
-                // visited set in REGISTERS: lane r holds the 64-bit column mask of compact row r.  The 3x3
-                // of a scan is 3 rows x 3 adjacent bits, tested and set with readlane/writelane + scalar ops:
-                // no LDS round trip in this sequential chain.
-                uint32_t vlo = 0, vhi = 0;
-                for (int kk = 0; kk < npiv; kk++) {
-                    const int L = __builtin_amdgcn_readlane(nscan, kk);
-                    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)movedmask, kk);
-                    bool cont = true;
-                    int Tk = 0;
+            const bool regmask = (pt.csx <= 64 && pt.csy <= 64);
+            // visited set in REGISTERS when it fits: lane r holds the 64-bit column mask of compact row r;
+            // a scan's 3x3 = 3 rows x 3 adjacent bits, tested/set with readlane + scalar ops (no LDS
+            // round trip in this sequential chain).  Otherwise the LDS bit array is used.
+            uint32_t vlo = 0, vhi = 0;
+            const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
+            for (int kk = 0; kk < npiv; kk++) {
+                const unsigned long long tr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(traj >> 32), kk) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)traj, kk);
+                int qu = __builtin_amdgcn_readlane(start_u, kk), qv = __builtin_amdgcn_readlane(start_v, kk);
+                bool cont = true;
+                int Tk = 0;
+                for (int t = 0; t < kSpecRounds; t++) {
+                    const int code = (int)((tr >> (4 * t)) & 15ull);
+                    if (code == 0 || !cont) break;
+                    int unv = 0;
+                    if (regmask) {
+                        const int ccx = qu - OCW, ccy = qv - OCW;
+                        const unsigned long long m3 = 7ull << (ccx - 1);
 #pragma unroll
-                    for (int t = 0; t < kSpecRounds; t++) {
-                        if (t < L && cont) {
-                            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)posr[t], kk);
-                            const int ccx = (int)(pk & 0xffffu) - OCW, ccy = (int)(pk >> 16) - OCW;
-                            const unsigned long long m3 = 7ull << (ccx - 1);
-                            int unv = 0;
-#pragma unroll
-                            for (int j = -1; j <= 1; j++) {
-                                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vhi, ccy + j) << 32) |
-                                                             (uint32_t)__builtin_amdgcn_readlane((int)vlo, ccy + j);
-                                unv += __builtin_popcountll(~m & m3);
-                                const unsigned long long mn = m | m3;
-                                const bool mine = (lane == ccy + j);
-                                vlo = mine ? (uint32_t)mn : vlo;
-                                vhi = mine ? (uint32_t)(mn >> 32) : vhi;
-                            }
-                            Tk = t + 1;
-                            cont = ((mm >> t) & 1u) && (unv != 0);
+                        for (int j = -1; j <= 1; j++) {
+                            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vhi, ccy + j) << 32) |
+                                                         (uint32_t)__builtin_amdgcn_readlane((int)vlo, ccy + j);
+                            unv += __builtin_popcountll(~m & m3);
+                            const unsigned long long mn = m | m3;
+                            const bool mine = (lane == ccy + j);
+                            vlo = mine ? (uint32_t)mn : vlo;
+                            vhi = mine ? (uint32_t)(mn >> 32) : vhi;
                         }
+                    } else {
+                        const int vb = (lane < 9) ? (qv + c2 - OCW) * vpitch + (qu + c1 - OCW) : 0;
+                        const bool unvis = (lane < 9) && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
+                        unv = __popcll(__ballot(unvis));
+                        if (unvis) atomicOr(&vis[vb >> 5], 1u << (vb & 31));
                     }
-                    if (lane == kk) T = Tk;
+                    Tk = t + 1;
+                    const bool moved = (code <= 9) && (code != 5);
+                    if (moved) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; qu += q3 - 1; qv += (mv - 3 * q3) - 1; }
+                    cont = moved && (unv != 0);
                 }
-                MIMC3_STAMP(6)
-                // publish the visited rows for the fit (bit array in LDS)
-                for (int c = 0; c < pt.csx; c++) {
-                    const bool on = (lane < pt.csy) && (((c < 32 ? vlo >> c : vhi >> (c - 32)) & 1u) != 0u);
-                    if (on) { const int cidx = lane * pt.csx + c; atomicOr(&vis[cidx >> 5], 1u << (cidx & 31)); }
-                }
-            } else {
-                const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
-                for (int kk = 0; kk < npiv; kk++) {
-                    const int L = __builtin_amdgcn_readlane(nscan, kk);
-                    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)movedmask, kk);
-                    bool cont = true;
-                    int Tk = 0;
-#pragma unroll
-                    for (int t = 0; t < kSpecRounds; t++) {
-                        if (t < L && cont) {
-                            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)posr[t], kk);
-                            const int cidx = (lane < 9) ? ((int)(pk >> 16) + c2 - OCW) * pt.csx + ((int)(pk & 0xffffu) + c1 - OCW) : 0;
-                            const bool unvis = (lane < 9) && (((vis[cidx >> 5] >> (cidx & 31)) & 1u) == 0u);
-                            const unsigned long long um = __ballot(unvis);
-                            if (unvis) atomicOr(&vis[cidx >> 5], 1u << (cidx & 31));
-                            Tk = t + 1;
-                            cont = ((mm >> t) & 1u) && (um != 0ull);
-                        }
-                    }
-                    if (lane == kk) T = Tk;
-                }
+                if (lane == kk) T = Tk;
+            }
+            if (regmask && lane < pt.csy) {   // publish the visited rows for the fit (csx <= 64: vpitch is 32 or 64)
+                vis[(lane * vpitch) >> 5] = vlo;
+                if (vpitch > 32) vis[((lane * vpitch) >> 5) + 1] = vhi;
             }
             MIMC3_STAMP(7)
-            if (p.debug_stop == 7) { if (lane == 0) p.out[3 * (size_t)gidx] = (float)T; return; }
-            // lane k: where pivot k ended and with which maximum (:744-752)
-            uint32_t fpos = posr[0];
-            float fmax = -2.0f;
-#pragma unroll
-            for (int t = 0; t < kSpecRounds; t++)
-                if (T == t + 1) { fpos = posr[t + 1]; fmax = smr[t]; }
+            // lane k: where pivot k ended and with which maximum (:744-752): after the last updating scan
+            // the pivot sits on the arg-max cell, so the running maximum is that cell's NCC
+            int fu = start_u, fv = start_v;
+            bool upd = false;
+            for (int t = 0; t < T; t++) {
+                const int code = (int)((traj >> (4 * t)) & 15ull);
+                if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
+            }
+            const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
+            const float fmax = upd ? val[(fv - OCW) * pt.csx + (fu - OCW)] : -2.0f;
             float bv = (lane < npiv) ? fmax : -__builtin_inff();
             int bi = lane;
             argmax_row16(bv, bi);
@@ -616,14 +596,15 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             const int cx = pu + c1 - OCW, cy = pvv + c2 - OCW;
             const int cidx = act ? cy * pt.csx + cx : 0;
             const float v = val[cidx];
-            const bool unvis = act && (((vis[cidx >> 5] >> (cidx & 31)) & 1u) == 0u);
+            const int vb = act ? cy * vpitch + cx : 0;
+            const bool unvis = act && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
             const bool missing = unvis && (v == kUnknown || v == kWanted);
             if (__ballot(missing)) {
                 if (missing) { val[cidx] = kUnknown; request(cx, cy); }
                 break;
             }
             newncc = __popcll(__ballot(unvis));
-            if (unvis) atomicOr(&vis[cidx >> 5], 1u << (cidx & 31));
+            if (unvis) atomicOr(&vis[vb >> 5], 1u << (vb & 31));
             float bv = (act && v == v) ? v : -__builtin_inff();
             int bi = lane;
             argmax_row16(bv, bi);                       // lanes 0..15 now hold (max, first index attaining it)
@@ -647,7 +628,8 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const int cidx = (peak_v - 1 + r - OCW) * pt.csx + (peak_u - 1 + c - OCW);
-                n9[3 * r + c] = ((vis[cidx >> 5] >> (cidx & 31)) & 1u) ? val[cidx] : -2.0f;
+                const int vb = (peak_v - 1 + r - OCW) * vpitch + (peak_u - 1 + c - OCW);
+                n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? val[cidx] : -2.0f;
             }
         double cp0, cp1, cp2, cp3, cp4;
         cp0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
@@ -702,7 +684,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     a.lds_list_cap = 9 * max_npiv + 16;
     size_t off = (size_t)a.lds_pw * Dy2;
     off = (off + 15) & ~(size_t)15; a.lds_off_val = (int)off; off += 4 * (size_t)cells;
-    off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
+    off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
     off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 16;
     off = (off + 15) & ~(size_t)15; a.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;

@@ -161,3 +161,46 @@ def synth_candidates(dimx, dimy, seed=5, k=8, p_out=0.45, sigma_in=0.06, out_amp
         dp[j, :, 1] = dv
         dp[j, :, 2] = rng.uniform(0.2, 1.0, n)
     return dp
+
+
+def synth_qm_state(dimx, dimy, seed=5, k=8, p_out=0.45, sigma_in=0.06, out_amp=5.0, p_wrong=0.3):
+    """Vectorised synthetic QM input for large grids (BASELINE config C5): per grid point one inlier
+    cluster (mean of the inlier candidates around a smooth true field) plus one singleton cluster
+    per outlier candidate, padded to [N][k][5]; the initial pick `dpf` is the inlier cluster when its
+    fraction exceeds 0.6 (get_dpf0's rule, MIMC_module.c:913) and otherwise the inlier cluster with
+    probability 1-p_wrong or a random outlier (a wrong snap that the pseudo-smoothing must repair).
+    Returns (mvn [N][k][5] f32, nclus [N] i32, dpf [dimy][dimx] i32, dx, dy [dimy][dimx] f32)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = dimx * dimy
+    ix, iy = np.meshgrid(np.arange(dimx), np.arange(dimy))
+    tu = (4.0 + 1.5 * np.sin(2 * np.pi * ix / dimx) * np.cos(2 * np.pi * iy / dimy)).reshape(-1)
+    tv = (-4.0 + 1.5 * np.cos(2 * np.pi * ix / dimx)).reshape(-1)
+    outl = rng.random((n, k)) < p_out
+    n_out = outl.sum(1)
+    n_in = k - n_out
+    mvn = np.zeros((n, k, 5), np.float32)
+    has_in = n_in > 0
+    sd = sigma_in / np.sqrt(np.maximum(n_in, 1))
+    mvn[:, 0, 0] = np.where(has_in, tu + rng.normal(0, 1, n) * sd, 0)
+    mvn[:, 0, 1] = np.where(has_in, tv + rng.normal(0, 1, n) * sd, 0)
+    mvn[:, 0, 2] = np.where(has_in, sigma_in ** 2 * (1 - 1 / np.maximum(n_in, 1)), 0)
+    mvn[:, 0, 3] = mvn[:, 0, 2]
+    mvn[:, 0, 4] = n_in / k
+    # outlier singletons occupy slots first_out .. first_out + n_out - 1
+    first_out = has_in.astype(np.int64)
+    rank = np.cumsum(outl, 1) - 1                                  # index of each outlier among the point's outliers
+    slot = first_out[:, None] + rank
+    pi, pj = np.nonzero(outl)
+    ou = tu[pi] + rng.uniform(-out_amp, out_amp, pi.size)
+    ov = tv[pi] + rng.uniform(-out_amp, out_amp, pi.size)
+    mvn[pi, slot[pi, pj], 0] = ou
+    mvn[pi, slot[pi, pj], 1] = ov
+    mvn[pi, slot[pi, pj], 4] = 1.0 / k
+    nclus = (first_out + n_out).astype(np.int32)
+    dpf = np.zeros(n, np.int32)
+    wrong = (mvn[:, 0, 4] <= 0.6) & (n_out > 0) & ((rng.random(n) < p_wrong) | ~has_in)
+    pick = first_out + (rng.integers(0, 1 << 30, n) % np.maximum(n_out, 1))
+    dpf[wrong] = pick[wrong]
+    dx = mvn[np.arange(n), dpf, 0].reshape(dimy, dimx).copy()
+    dy = mvn[np.arange(n), dpf, 1].reshape(dimy, dimx).copy()
+    return mvn, nclus, dpf.reshape(dimy, dimx), dx, dy
