@@ -53,6 +53,7 @@ struct mimc3_ctx {
     DevBuf own_i0, own_i1;              // used when images were uploaded from the host
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
+    DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
     int32_t Wp = 0;
     bool u8_ok = false;                 // both images proven to be integers in [0,255]
     int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
@@ -101,7 +102,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
-    c->pl0.release(); c->pl1.release(); c->flag.release();
+    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -214,7 +215,18 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W;
         u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
         u.piv_uv = d_piv_uv; u.piv_off = d_piv_off; u.ocw = ocw; u.swap = swap ? 1 : 0; u.out = d_out;
+        // points whose per-point NCC cache overflows (very long climbs) are appended to a device list and
+        // redone by the general kernel right behind, in list mode: no host round trip
+        HIP_TRY(c->ovf.reserve(sizeof(int32_t) * ((size_t)N + 1)));
+        HIP_TRY(hipMemsetAsync(c->ovf.p, 0, sizeof(int32_t), s));
+        u.ovf_count = static_cast<int32_t *>(c->ovf.p);
+        u.ovf_list = u.ovf_count + 1;
         e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+        if (e == hipSuccess) {
+            a.point_count = u.ovf_count;
+            a.point_list = u.ovf_list;
+            e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+        }
         c->last_path = 1;
     } else {
         e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);

@@ -19,6 +19,8 @@ struct MatchArgs {
     int32_t swap;                // 0: chip from i0, window from i1; 1: exchanged
     float thr;                   // smallest f32 whose f64 value is >= MIN_DN (1e-10, MIMC_module.c:21)
     float *out;                  // device [N][3]
+    const int32_t *point_list;   // optional: process only these point indices (device list) ...
+    const int32_t *point_count;  // ... whose length is read on the device (nullptr = all N points)
     // LDS carve (floats / pivots), filled by the launcher from the per-launch maxima
     int32_t lds_chip_f, lds_win_f, lds_cell_f, lds_npiv;
 };
@@ -37,8 +39,10 @@ struct MatchU8Args {
     const int64_t *piv_off;
     int32_t ocw, swap;
     float *out;
+    int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
     // LDS carve, filled by the launcher
-    int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
+    int32_t lds_pw, lds_off_val, lds_off_ncc, lds_off_req, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
+    int32_t cache_cap, map_u16;     // NCC cache slots per point; cell->slot map element width
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off
 };

@@ -100,20 +100,10 @@ __device__ __forceinline__ float eval_cell(const float *chip, const Win<WIN_LDS>
 }
 
 template <bool WIN_LDS>
-__global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
+__device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kMatchThreads / 64;
-
-    // XCD-aware point order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-    // contiguous run of grid points (neighbours share most of their window rows in that L2).
-    int gidx = blockIdx.x;
-    {
-        const int nb = gridDim.x, per = nb >> 3;
-        if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-    }
-    if (gidx >= p.N) return;
 
     const float *chip_img = p.swap ? p.i1 : p.i0;
     const float *win_img = p.swap ? p.i0 : p.i1;
@@ -330,6 +320,31 @@ __global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
     }
 }
 
+template <bool WIN_LDS>
+__global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.point_list) {
+        // list mode: re-run of the few points another kernel handed back (u8 path cache overflow);
+        // a small persistent grid strides over the device-side list
+        const int cnt = *p.point_count;
+        for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+            match_point_f32<WIN_LDS>(p, p.point_list[i], smem);
+            __syncthreads();
+        }
+        return;
+    }
+    // XCD-aware point order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of grid points (neighbours share most of their window rows in that L2).
+    int gidx = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3;
+        if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+    }
+    if (gidx >= p.N) return;
+    match_point_f32<WIN_LDS>(p, gidx, smem);
+}
+
 // ---- host-side launcher --------------------------------------------------------------------------
 static size_t lds_layout(MatchArgs &a, int ocw, int max_abs_u, int max_abs_v, int max_npiv, bool win_lds)
 {
@@ -365,7 +380,8 @@ hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_n
         if (bytes > kLdsCap) return hipErrorInvalidValue;
     }
     // grid rounded up to a multiple of 8 so the XCD remap is a bijection on [0, 8*per)
-    const unsigned nb = (unsigned)((a.N + 7) & ~7);
+    unsigned nb = (unsigned)((a.N + 7) & ~7);
+    if (a.point_list) nb = nb < 1024u ? nb : 1024u;      // list mode: small persistent grid
     if (win_lds)
         hipLaunchKernelGGL(match_ncc_dlc_f32<true>, dim3(nb), dim3(kMatchThreads), bytes, stream, a);
     else

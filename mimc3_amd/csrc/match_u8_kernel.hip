@@ -229,17 +229,32 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
-    float *val = reinterpret_cast<float *>(smem + p.lds_off_val);         // [csy][csx] NCC cache
-    uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits
-    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // packed cells (cy<<16|cx): clean boxes from the front, dirty from the back
+    // NCC cache: a cell that has been requested owns slot map[cell]-1 of nccv[] (0 = never requested)
+    unsigned char *cmap8 = smem + p.lds_off_val;                          // [csy][csx] u8  (cap <= 255)
+    uint16_t *cmap16 = reinterpret_cast<uint16_t *>(smem + p.lds_off_val);//           or u16
+    float *nccv = reinterpret_cast<float *>(smem + p.lds_off_ncc);        // [cap]
+    uint32_t *reqb = reinterpret_cast<uint32_t *>(smem + p.lds_off_req);  // requested bits [ncell]
+    uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits, rows padded to words
+    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // packed cells (slot<<16|cy<<8|cx): clean boxes from the front, dirty from the back
     uint32_t *sums = reinterpret_cast<uint32_t *>(smem + p.lds_off_sums); // [kSumBatch][6]
     int32_t *pivs = reinterpret_cast<int32_t *>(smem + p.lds_off_piv);    // [npiv][2]
-    const int lcap = p.lds_list_cap;
+    const int lcap = p.lds_list_cap, cap = p.cache_cap;
+    const bool map16 = p.map_u16 != 0;
 
-    for (int i = lane; i < pt.ncell; i += 64) val[i] = kUnknown;
+    {
+        const int nmapw = map16 ? ((pt.ncell + 1) >> 1) : ((pt.ncell + 3) >> 2);
+        uint32_t *mw = reinterpret_cast<uint32_t *>(smem + p.lds_off_val);
+        for (int i = lane; i < nmapw; i += 64) mw[i] = 0u;
+        for (int i = lane; i < ((pt.ncell + 31) >> 5); i += 64) reqb[i] = 0u;
+    }
     const int vpitch = ((pt.csx + 31) >> 5) << 5;          // visited bits: one row = whole 32-bit words
     for (int i = lane; i < ((pt.csy * vpitch) >> 5); i += 64) vis[i] = 0u;
     for (int i = lane; i < 2 * npiv; i += 64) pivs[i] = pv_g[i];
+    // NCC of a compact cell, kUnknown when it has not been evaluated
+    auto lookup = [&](int cell) __attribute__((always_inline)) -> float {
+        const int sl = map16 ? (int)cmap16[cell] : (int)cmap8[cell];
+        return sl ? nccv[sl - 1] : kUnknown;
+    };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
     int bad_win = 0;
@@ -359,12 +374,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             return;
         }
     }
-    if (OCW == 1)   // T4 cmap cells (only reachable by the fit when ocw == 1)
-        for (int i = lane; i < pt.ncell; i += 64) {
-            const int cy = i / pt.csx, cx = i - cy * pt.csx;
-            if (cx + OCW == pt.Dx2 - 1 || cy + OCW == pt.Dy2 - 1) { val[i] = 0.0f; const int vb = cy * vpitch + cx; atomicOr(&vis[vb >> 5], 1u << (vb & 31)); }
-        }
-
+    static_assert(OCW >= 2, "T4 cmap cells are reachable by the fit only when ocw == 1; not instantiated");
     // a cell's 33x33 (CW x CW) box of the window is null-free iff it avoids the null bounding box and
     // the zero last row/column (T4)
     auto box_clean = [&](int cx, int cy) __attribute__((always_inline)) -> bool {
@@ -375,13 +385,18 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
 
     // ---- request queue: a cell is requested at most once (CAS on its cache slot); clean boxes are
     //      queued from the front of `list`, dirty boxes from the back ------------------------------
-    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // [0] clean count, [1] dirty count
-    if (lane < 2) qcnt[lane] = 0;
+    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // [0] clean queued, [1] dirty queued, [2] slots used, [3] overflow
+    if (lane < 4) qcnt[lane] = 0;
     __syncthreads();
     auto request = [&](int cx, int cy) __attribute__((always_inline)) {
-        int *slot = reinterpret_cast<int *>(&val[cy * pt.csx + cx]);
-        if (atomicCAS(slot, __float_as_int(kUnknown), __float_as_int(kWanted)) != __float_as_int(kUnknown)) return;
-        const uint32_t packed = ((uint32_t)cy << 16) | (uint32_t)cx;
+        const int cell = cy * pt.csx + cx;
+        const uint32_t bit = 1u << (cell & 31);
+        if (atomicOr(&reqb[cell >> 5], bit) & bit) return;                 // somebody already asked for it
+        const int slot = atomicAdd(&qcnt[2], 1);
+        if (slot >= cap) { qcnt[3] = 1; return; }                          // cache full: the point is handed to the general kernel
+        if (map16) cmap16[cell] = (uint16_t)(slot + 1); else cmap8[cell] = (unsigned char)(slot + 1);
+        nccv[slot] = kWanted;
+        const uint32_t packed = ((uint32_t)slot << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
         if (box_clean(cx, cy)) list[atomicAdd(&qcnt[0], 1)] = packed;
         else list[lcap - 1 - atomicAdd(&qcnt[1], 1)] = packed;
     };
@@ -406,8 +421,8 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             for (int r0 = 0; r0 < nb; r0 += C::CPR) {
                 const int slot = r0 + grp;
                 const bool on = slot < nb;
-                const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00010001u;
-                const int cx = (int)(pk & 0xffffu), cy = (int)(pk >> 16);
+                const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00000101u;
+                const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 Acc acc;
                 if (mode == M_FAST) {
                     acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             if (lane < nb) {
                 const uint32_t *sp = sums + 6 * lane;
                 const uint32_t pk = ids[dir * (b0 + lane)];
-                val[(int)(pk >> 16) * pt.csx + (int)(pk & 0xffffu)] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
+                nccv[pk >> 16] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
             }
             __syncthreads();
         }
@@ -457,6 +472,10 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     int peak_u = pt.dx2, peak_v = pt.dy2;
 
     for (int guard = 0; guard <= pt.ncell + 16; guard++) {
+        if (qcnt[3]) {                                   // NCC cache overflow: let the general kernel redo this point
+            if (lane == 0) p.ovf_list[atomicAdd(p.ovf_count, 1)] = gidx;
+            return;
+        }
         {   // evaluate everything queued, then empty the queue (the only call site of `evaluate`)
             const int nA = qcnt[0], nB = qcnt[1];
             __syncthreads();
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
                 int mv = -1;
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
-                    const float v = val[(sv + (j % 3 - 1) - OCW) * pt.csx + (su + (j / 3 - 1) - OCW)];
+                    const float v = lookup((sv + (j % 3 - 1) - OCW) * pt.csx + (su + (j / 3 - 1) - OCW));
                     if (v > smax && v < 2.5f) { smax = v; mv = j; }   // NaN never wins; unknown sentinels (>= 3) ignored
                 }
                 const bool moved = (mv >= 0 && mv != 4);
@@ -557,7 +576,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
                 if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
             }
             const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
-            const float fmax = upd ? val[(fv - OCW) * pt.csx + (fu - OCW)] : -2.0f;
+            const float fmax = upd ? lookup((fv - OCW) * pt.csx + (fu - OCW)) : -2.0f;
             float bv = (lane < npiv) ? fmax : -__builtin_inff();
             int bi = lane;
             argmax_row16(bv, bi);
@@ -595,12 +614,12 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
             const int cx = pu + c1 - OCW, cy = pvv + c2 - OCW;
             const int cidx = act ? cy * pt.csx + cx : 0;
-            const float v = val[cidx];
+            const float v = lookup(cidx);
             const int vb = act ? cy * vpitch + cx : 0;
             const bool unvis = act && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
             const bool missing = unvis && (v == kUnknown || v == kWanted);
             if (__ballot(missing)) {
-                if (missing) { val[cidx] = kUnknown; request(cx, cy); }
+                if (missing) request(cx, cy);
                 break;
             }
             newncc = __popcll(__ballot(unvis));
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
             for (int c = 0; c < 3; c++) {
                 const int cidx = (peak_v - 1 + r - OCW) * pt.csx + (peak_u - 1 + c - OCW);
                 const int vb = (peak_v - 1 + r - OCW) * vpitch + (peak_u - 1 + c - OCW);
-                n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? val[cidx] : -2.0f;
+                n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? lookup(cidx) : -2.0f;
             }
         double cp0, cp1, cp2, cp3, cp4;
         cp0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
@@ -681,9 +700,17 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     const int csx = Dx2 - 2 * C::OCW + 1;
     const int pw_a = ((3 + (Dx2 - 1) + 3) >> 2) + 1, pw_b = ((3 + csx - 2) >> 2) + C::GPR + 1;
     a.lds_pw = 4 * (pw_a > pw_b ? pw_a : pw_b);
-    a.lds_list_cap = 9 * max_npiv + 16;
+    static const int slack = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 64;   // tests shrink it to force the overflow path
+    int cap = 9 * max_npiv + slack;
+    if (cap > cells) cap = cells;
+    if (cap < 16) cap = 16;
+    a.cache_cap = cap;
+    a.map_u16 = cap > 255 ? 1 : 0;
+    a.lds_list_cap = cap + 16;
     size_t off = (size_t)a.lds_pw * Dy2;
-    off = (off + 15) & ~(size_t)15; a.lds_off_val = (int)off; off += 4 * (size_t)cells;
+    off = (off + 15) & ~(size_t)15; a.lds_off_val = (int)off; off += (size_t)cells * (a.map_u16 ? 2 : 1);
+    off = (off + 15) & ~(size_t)15; a.lds_off_ncc = (int)off; off += 4 * (size_t)cap;
+    off = (off + 15) & ~(size_t)15; a.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
     off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
     off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 16;
@@ -728,8 +755,9 @@ bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v)
 {
     if (!(ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40)) return false;
     // the window hangs over the image edge by at most |last pivot| + |CP offset| + 2 pixels (+ up to 7
-    // bytes of aligned read-ahead): all of it must stay inside the zero border
-    return max_reach_u + 12 <= kU8Pad && max_reach_v + 12 <= kU8Pad;
+    // bytes of aligned read-ahead): all of it must stay inside the zero border; compact cell coordinates
+    // are packed in 8 bits (csx = 2|last|+6 <= 255)
+    return max_reach_u + 12 <= kU8Pad && max_reach_v + 12 <= kU8Pad && max_reach_u <= 120 && max_reach_v <= 120;
 }
 
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)

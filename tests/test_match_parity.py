@@ -123,6 +123,41 @@ def test_long_climbs(api, oracle, mode):
     assert np.abs(np.nanmedian(got[:, 0]) - 13) < 0.5
 
 
+def test_u8_cache_overflow_hands_points_to_general_kernel(oracle):
+    """Shrink the u8 kernel's per-point NCC cache (debug env knob) so that every point overflows: the
+    points are appended to a device list and redone by the general kernel in list mode."""
+    import subprocess, sys, os, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from mimc3_amd import api, synth
+        c = synth.make_small(seed=95, shift=(3, -3), angle_deg=45.0, ocw=16, speed=1806.0, h=240, w=240, dimx=6, dimy=6,
+                             noise_dn=2, null_frac=0.04)
+        H, W = c.i0.shape
+        off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+        with api.Context(0) as ctx:
+            ctx.set_images(c.i0, c.i1)
+            got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+            assert ctx.last_path() == "u8_exact"
+        np.save(sys.argv[1], got)
+    """ % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for slack in ("-100", "64"):
+            f = os.path.join(d, f"o{slack}.npy")
+            subprocess.check_call([sys.executable, "-c", code, f], env=dict(os.environ, MIMC3_U8_CACHE_SLACK=slack))
+            outs.append(np.load(f))
+    c = synth.make_small(seed=95, shift=(3, -3), angle_deg=45.0, ocw=16, speed=1806.0, h=240, w=240, dimx=6, dimy=6,
+                         noise_dn=2, null_frac=0.04)
+    H, W = c.i0.shape
+    off, uv = oracle.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    assert_bits_equal(outs[0], want, "all points overflowed")
+    assert_bits_equal(outs[1], want, "normal cache")
+
+
 def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
     """The CLI's schedule: ocw 7, 15, 30, 40 forward + swapped on one resident pair (MIMC_main.c:261-300)."""
     c = synth.make_small(seed=61, shift=(3, -3), angle_deg=45.0, ocw=40, speed=1200.0, h=330, w=340, dimx=5, dimy=5,
