@@ -174,6 +174,12 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
         }
+        try:   # HBM bytes per launch measured by rocprofv3 PMC passes of this same command (profiles/)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[args.config][res["roofline"]["kernel"]]
+            res["roofline"]["traffic"] = tr["bytes"]
+            res["roofline"]["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+        except Exception:
+            pass
         got = d_out[:n].cpu().numpy()
         valid = got[:, 2] > -2.5
         res["check"] = {"valid_frac": float(valid.mean()),
