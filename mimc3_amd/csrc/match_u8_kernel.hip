@@ -187,8 +187,9 @@ static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in
         t_prev = t_now;                                                                        \
     }
 
+// occupancy target: 4 waves per SIMD (<= 128 VGPRs) for the chips whose register image allows it
 template <class C>
-__global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
+__global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void match_ncc_dlc_u8(MatchU8Args p)
 {
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -403,12 +404,50 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
         return !(pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1);
     };
+    // request the whole 3x3 around compact cell (cx0, cy0) with THREE dependent LDS round trips instead
+    // of up to 27: the nine "requested" bit-sets are issued together, one counter bump reserves the
+    // cache slots of the cells this lane won, one bump per class reserves the queue entries
+    auto request9 = [&](int cx0, int cy0) __attribute__((always_inline)) {
+        uint32_t old[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const int cell = (cy0 + (j % 3 - 1)) * pt.csx + cx0 + (j / 3 - 1);
+            old[j] = atomicOr(&reqb[cell >> 5], 1u << (cell & 31));
+        }
+        uint32_t won = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const int cell = (cy0 + (j % 3 - 1)) * pt.csx + cx0 + (j / 3 - 1);
+            if (!((old[j] >> (cell & 31)) & 1u)) won |= 1u << j;
+        }
+        if (!won) return;
+        const int nw = __popc(won);
+        int slot = atomicAdd(&qcnt[2], nw);
+        if (slot + nw > cap) { qcnt[3] = 1; return; }                       // cache full: the point goes to the general kernel
+        uint32_t cl = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (((won >> j) & 1u) && box_clean(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1))) cl |= 1u << j;
+        const uint32_t wa = won & cl, wb = won & ~cl;
+        int ia = wa ? atomicAdd(&qcnt[0], __popc(wa)) : 0;
+        int ib = wb ? atomicAdd(&qcnt[1], __popc(wb)) : 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            if (!((won >> j) & 1u)) continue;
+            const int cx = cx0 + (j / 3 - 1), cy = cy0 + (j % 3 - 1);
+            const int cell = cy * pt.csx + cx;
+            if (map16) cmap16[cell] = (uint16_t)(slot + 1); else cmap8[cell] = (unsigned char)(slot + 1);
+            nccv[slot] = kWanted;
+            const uint32_t packed = ((uint32_t)slot << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+            if ((wa >> j) & 1u) list[ia++] = packed; else list[lcap - 1 - ib++] = packed;
+            slot++;
+        }
+    };
     // round 0 = the certain set: every pivot whose start passes the boundary test scans its whole 3x3
     for (int k = lane; k < npiv; k += 64) {
         const int pu = pivs[2 * k] + pt.dx2, pvv = pivs[2 * k + 1] + pt.dy2;
         if (!inside(pu, pvv)) continue;
-#pragma unroll
-        for (int j = 0; j < 9; j++) request(pu + (j / 3 - 1) - OCW, pvv + (j % 3 - 1) - OCW);
+        request9(pu - OCW, pvv - OCW);
     }
     __syncthreads();
     if (p.debug_stop == 3) return;
@@ -464,6 +503,7 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
     // lane k's speculative trajectory as 4-bit codes per scan: 0 = no scan, 1..9 = the scan updated the
     // running maximum at 3x3 index code-1 (5 = centre: no move), 10 = scanned without update
     unsigned long long traj = 0ull;
+    int nsc = 0;                                     // scans recorded so far
     bool replay_generic = false;
     // wave-uniform state of the reference's loops (:691-753)
     int k = 0, pu = 0, pvv = 0, du = 0, dv = 0, newncc = 0;
@@ -487,29 +527,41 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
         if (p.debug_stop == 4) return;
         MIMC3_STAMP(3)
         if (stage < kSpecRounds) {
-            if (alive) {
+            // each alive lane keeps scanning while its whole 3x3 is cached (values evaluated for other
+            // pivots count too); when it runs into unknown cells it queues them, plus the 3x3 one step
+            // further in the direction it just moved (lookahead: straight climbs advance 2 scans per batch)
+            int ldu = 0, ldv = 0;
+            while (alive && nsc < kSpecRounds) {
                 int mv = -1;
+                float sm = smax;
+                bool known = true;
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
                     const float v = lookup((sv + (j % 3 - 1) - OCW) * pt.csx + (su + (j / 3 - 1) - OCW));
-                    if (v > smax && v < 2.5f) { smax = v; mv = j; }   // NaN never wins; unknown sentinels (>= 3) ignored
+                    known = known && !(v >= 2.5f);                  // 3.0 / 4.0 = not evaluated yet (NaN is a value)
+                    if (v > sm) { sm = v; mv = j; }                 // NaN never wins (:736)
                 }
+                if (!known) break;                                   // wait for the batch that holds the missing cells
+                smax = sm;
                 const bool moved = (mv >= 0 && mv != 4);
-                if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; }
-                traj |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * stage);
+                ldu = moved ? mv / 3 - 1 : 0; ldv = moved ? mv % 3 - 1 : 0;
+                su += ldu; sv += ldv;
+                traj |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * nsc);
+                nsc++;
                 alive = moved && inside(su, sv);
-                if (alive) {
-#pragma unroll
-                    for (int j = 0; j < 9; j++) request(su + (j / 3 - 1) - OCW, sv + (j % 3 - 1) - OCW);
-                }
+            }
+            if (alive && nsc < kSpecRounds) {
+                request9(su - OCW, sv - OCW);
+                if ((ldu | ldv) != 0 && inside(su + ldu, sv + ldv)) request9(su + ldu - OCW, sv + ldv - OCW);
             }
             __syncthreads();
             stage++;
             MIMC3_STAMP(4)
-            if (__any(alive) && stage < kSpecRounds) continue;   // next speculative scan (after evaluating its requests)
-            replay_generic = (npiv > 64) || __any(alive);          // a climb longer than kSpecRounds: exact generic replay
+            const bool more = __any(alive && nsc < kSpecRounds);
+            if (more && qcnt[0] + qcnt[1] != 0) continue;          // evaluate the queued cells, then scan on
+            replay_generic = (npiv > 64) || __any(alive);           // a climb longer than kSpecRounds scans: generic replay
             stage = kSpecRounds;
-            if (qcnt[0] + qcnt[1] != 0) continue;                  // (generic case) evaluate what was queued first
+            if (qcnt[0] + qcnt[1] != 0) continue;                   // (generic case) evaluate what was queued first
         }
         if (p.debug_stop == 5) return;
         if (!replay_generic) {
@@ -537,18 +589,15 @@ __global__ __launch_bounds__(64) void match_ncc_dlc_u8(MatchU8Args p)
                     if (code == 0 || !cont) break;
                     int unv = 0;
                     if (regmask) {
+                        // the three rows ccy-1..ccy+1 test and set their own 3 bits in parallel
                         const int ccx = qu - OCW, ccy = qv - OCW;
                         const unsigned long long m3 = 7ull << (ccx - 1);
-#pragma unroll
-                        for (int j = -1; j <= 1; j++) {
-                            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vhi, ccy + j) << 32) |
-                                                         (uint32_t)__builtin_amdgcn_readlane((int)vlo, ccy + j);
-                            unv += __builtin_popcountll(~m & m3);
-                            const unsigned long long mn = m | m3;
-                            const bool mine = (lane == ccy + j);
-                            vlo = mine ? (uint32_t)mn : vlo;
-                            vhi = mine ? (uint32_t)(mn >> 32) : vhi;
-                        }
+                        const bool mine = (unsigned)(lane - (ccy - 1)) < 3u;
+                        const unsigned long long m = ((unsigned long long)vhi << 32) | vlo;
+                        unv = __any(mine && ((~m & m3) != 0ull)) ? 1 : 0;
+                        const unsigned long long mn = m | m3;
+                        vlo = mine ? (uint32_t)mn : vlo;
+                        vhi = mine ? (uint32_t)(mn >> 32) : vhi;
                     } else {
                         const int vb = (lane < 9) ? (qv + c2 - OCW) * vpitch + (qu + c1 - OCW) : 0;
                         const bool unvis = (lane < 9) && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
