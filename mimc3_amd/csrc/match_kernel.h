@@ -42,6 +42,7 @@ struct MatchU8Args {
     int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
     // LDS carve, filled by the launcher
     int32_t lds_pw, lds_off_val, lds_off_ncc, lds_off_req, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
+    int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
     int32_t cache_cap, map_u16;     // NCC cache slots per point; cell->slot map element width
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off

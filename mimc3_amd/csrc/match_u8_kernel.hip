@@ -71,9 +71,10 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 #undef MIMC3_ARGMAX_STEP
 }
 
-template <int OCW_, int LPC_>
+template <int OCW_, int LPC_, int NW_ = 1>
 struct U8Cfg {
     static constexpr int OCW = OCW_, LPC = LPC_;
+    static constexpr int NW = NW_, NT = 64 * NW_;            // waves / threads per grid point (one workgroup)
     static constexpr int CW = 2 * OCW + 1, NPX = CW * CW;
     static constexpr int GPR = (CW + 3) / 4;                 // packed dwords per chip row
     static constexpr int RF = CW / LPC;                      // full rounds: rows l + LPC*i
@@ -101,9 +102,11 @@ enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2 };
 struct Acc { uint32_t n, sx, sy, sxx, syy, sxy; };
 
 template <int MODE>
-__device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t mf, uint32_t pad01, uint32_t padff, bool static_pad,
-                                     uint32_t bw)
+__device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t pad01, uint32_t padff, bool static_pad, uint32_t bw)
 {
+    // byte mask of the chip group: 0xFF where the chip pixel is valid (null pixels and the pad bytes of the
+    // last group are 0 in `a`), derived on the fly -- keeping it in registers would cost a second chip image
+    const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
     if (MODE == M_FAST) {
         // mf is exactly the pad mask here; for the unrolled full rows it is a compile-time constant
         const uint32_t m01 = static_pad ? pad01 : (mf & 0x01010101u);
@@ -133,9 +136,7 @@ __device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t mf, uint32_t
 template <class C, int MODE>
 __device__ __forceinline__ Acc eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
-                                          const uint32_t (&MF)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
-                                          const uint32_t (&MFT)[C::TT > 0 ? C::TT : 1],
                                           const int (&toff)[C::TT > 0 ? C::TT : 1])
 {
     Acc acc{0, 0, 0, 0, 0, 0};
@@ -153,14 +154,14 @@ __device__ __forceinline__ Acc eval_round(const unsigned char *W, const U8Point 
             const uint32_t bw = alignb(w[j + 1], w[j], s);
             const uint32_t p01 = (j == C::GPR - 1) ? C::LAST01 : 0x01010101u;
             const uint32_t pff = (j == C::GPR - 1) ? C::LASTFF : 0xffffffffu;
-            task<MODE>(acc, A[i][j], MF[i][j], p01, pff, true, bw);
+            task<MODE>(acc, A[i][j], p01, pff, true, bw);
         }
     }
 #pragma unroll
     for (int k = 0; k < C::TT; k++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + toff[k]);
         const uint32_t bw = alignb(rp[1], rp[0], s);
-        task<MODE>(acc, AT[k], MFT[k], 0, 0, false, bw);   // tail tasks carry their pad/null masks in MFT
+        task<MODE>(acc, AT[k], 0, 0, false, bw);   // tail tasks: pad/null masks come from the bytes of AT[k]
     }
     acc.sy = group_sum<C::LPC>(acc.sy); acc.syy = group_sum<C::LPC>(acc.syy); acc.sxy = group_sum<C::LPC>(acc.sxy);
     if (MODE == M_GENERAL) {
@@ -183,19 +184,19 @@ static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in
 #define MIMC3_STAMP(i)                                                                         \
     if (p.stats) {                                                                             \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
-        if (lane == 0) p.stats[8 * (size_t)blockIdx.x + i] += t_now - t_prev;                   \
+        if (threadIdx.x == 0) p.stats[8 * (size_t)blockIdx.x + i] += t_now - t_prev;                   \
         t_prev = t_now;                                                                        \
     }
 
 // occupancy target: 4 waves per SIMD (<= 128 VGPRs) for the chips whose register image allows it
 template <class C>
-__global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void match_ncc_dlc_u8(MatchU8Args p)
+__global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void match_ncc_dlc_u8(MatchU8Args p)
 {
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = lane & (C::LPC - 1), grp = lane / C::LPC;
-    constexpr int OCW = C::OCW, CW = C::CW, GPR = C::GPR;
+    constexpr int OCW = C::OCW, CW = C::CW, GPR = C::GPR, NT = C::NT, NW = C::NW;
 
     int gidx = blockIdx.x;
     {
@@ -245,12 +246,17 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
     {
         const int nmapw = map16 ? ((pt.ncell + 1) >> 1) : ((pt.ncell + 3) >> 2);
         uint32_t *mw = reinterpret_cast<uint32_t *>(smem + p.lds_off_val);
-        for (int i = lane; i < nmapw; i += 64) mw[i] = 0u;
-        for (int i = lane; i < ((pt.ncell + 31) >> 5); i += 64) reqb[i] = 0u;
+        for (int i = tid; i < nmapw; i += NT) mw[i] = 0u;
+        for (int i = tid; i < ((pt.ncell + 31) >> 5); i += NT) reqb[i] = 0u;
     }
     const int vpitch = ((pt.csx + 31) >> 5) << 5;          // visited bits: one row = whole 32-bit words
-    for (int i = lane; i < ((pt.csy * vpitch) >> 5); i += 64) vis[i] = 0u;
-    for (int i = lane; i < 2 * npiv; i += 64) pivs[i] = pv_g[i];
+    for (int i = tid; i < ((pt.csy * vpitch) >> 5); i += NT) vis[i] = 0u;
+    for (int i = tid; i < 2 * npiv; i += NT) pivs[i] = pv_g[i];
+    // control words: [0] clean queued, [1] dirty queued, [2] cache slots used, [3] cache overflow,
+    // [4] null pixels in the window, [5..8] their bounding box (x0,x1,y0,y1), [9] driver decision
+    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);
+    if (tid < 16) qcnt[tid] = (tid == 5 || tid == 7) ? (1 << 20) : ((tid == 6 || tid == 8) ? -1 : 0);
+    __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
     auto lookup = [&](int cell) __attribute__((always_inline)) -> float {
         const int sl = map16 ? (int)cmap16[cell] : (int)cmap8[cell];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
         const uint32_t last_ff = lastb ? ((1u << (8 * lastb)) - 1u) : 0xffffffffu;
         const uint32_t *gbase = reinterpret_cast<const uint32_t *>(win_pl + (size_t)wv0 * Wp + (wu0 & ~3));
         const int gpitch = Wp >> 2;
-        for (int idx = lane; idx < tot; idx += 64) {
+        for (int idx = tid; idx < tot; idx += NT) {
             const int r = (int)__umulhi((uint32_t)idx, inv);
             const int c = idx - r * nd;
             uint32_t v = gbase[(size_t)r * gpitch + c];
@@ -289,14 +295,22 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
         // after each row's last written dword (read by the sliding loads of the right-most cells)
         const int ndz = pt.PW >> 2;
-        for (int c = lane; c < ndz; c += 64) *reinterpret_cast<uint32_t *>(W + wrows * pt.PW + 4 * c) = 0u;
-        for (int r = lane; r < wrows; r += 64)
+        for (int c = tid; c < ndz; c += NT) *reinterpret_cast<uint32_t *>(W + wrows * pt.PW + 4 * c) = 0u;
+        for (int r = tid; r < wrows; r += NT)
             for (int c = nd; c < ndz; c++) *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = 0u;
         bad_win = wave_sum_i(bad_win);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             nbx0 = min(nbx0, __shfl_xor(nbx0, o, 64)); nbx1 = max(nbx1, __shfl_xor(nbx1, o, 64));
             nby0 = min(nby0, __shfl_xor(nby0, o, 64)); nby1 = max(nby1, __shfl_xor(nby1, o, 64));
+        }
+        if (NW > 1) {                                        // combine the waves' partial results through LDS
+            if (lane == 0) {
+                atomicAdd(&qcnt[4], bad_win);
+                atomicMin(&qcnt[5], nbx0); atomicMax(&qcnt[6], nbx1); atomicMin(&qcnt[7], nby0); atomicMax(&qcnt[8], nby1);
+            }
+            __syncthreads();
+            bad_win = qcnt[4]; nbx0 = qcnt[5]; nbx1 = qcnt[6]; nby0 = qcnt[7]; nby1 = qcnt[8];
         }
     }
     if (p.debug_stop == 1) return;
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
 
     // ---- chip -> registers (a4): every lane group holds the whole chip --------------------------
     constexpr int RFA = C::RF > 0 ? C::RF : 1, TTA = C::TT > 0 ? C::TT : 1;
-    uint32_t A[RFA][GPR], MF[RFA][GPR], AT[TTA], MFT[TTA];
+    uint32_t A[RFA][GPR], AT[TTA];
     int toff[TTA];
     int bad_chip = 0;
     uint32_t SX = 0, SXX = 0;
@@ -328,7 +342,6 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
                 a &= pff;
                 A[i][j] = a;
                 const uint32_t t = nz80(a);
-                MF[i][j] = ff_from80(t);
                 bad_chip += __popc(pff & 0x01010101u) - __popc(t >> 7);
                 SX = dot4(a, 0x01010101u, SX);
                 SXX = dot4(a, a, SXX);
@@ -345,7 +358,6 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
             a &= pff;
             AT[k] = a;
             const uint32_t t = nz80(a);
-            MFT[k] = ff_from80(t);
             toff[k] = rr * pt.PW + 4 * j;
             bad_chip += __popc(pff & 0x01010101u) - __popc(t >> 7);
             SX = dot4(a, 0x01010101u, SX);
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
     pt.SX = SX; pt.SXX = SXX; pt.NV = (uint32_t)(C::NPX - bad_chip);
     const int clean_mode = (bad_chip == 0) ? M_FAST : M_CHIPNULL;
     MIMC3_STAMP(1)
-    if (p.debug_stop == 2) { if (lane == 0) p.out[3 * (size_t)gidx] = (float)(SX + SXX + bad_chip + A[0][0] + AT[0]); return; }
+    if (p.debug_stop == 2) { if (tid == 0) p.out[3 * (size_t)gidx] = (float)(SX + SXX + bad_chip + A[0][0] + AT[0]); return; }
     __syncthreads();   // single-wave workgroup: orders the LDS stores above before the reads below
 
     // ---- validity (a6, :635) --------------------------------------------------------------------
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
         const float rc = (float)bad_chip / (float)(CW * CW);
         const float rw = (float)bad_win / (float)(pt.Dx2 * pt.Dy2);
         if (rc > max_ratio || rw > max_ratio) {
-            if (lane == 0) {
+            if (tid == 0) {
                 const float nanv = __builtin_nanf("");
                 p.out[3 * (size_t)gidx + 0] = nanv;
                 p.out[3 * (size_t)gidx + 1] = nanv;
@@ -386,9 +398,6 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
 
     // ---- request queue: a cell is requested at most once (CAS on its cache slot); clean boxes are
     //      queued from the front of `list`, dirty boxes from the back ------------------------------
-    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // [0] clean queued, [1] dirty queued, [2] slots used, [3] overflow
-    if (lane < 4) qcnt[lane] = 0;
-    __syncthreads();
     auto request = [&](int cx, int cy) __attribute__((always_inline)) {
         const int cell = cy * pt.csx + cx;
         const uint32_t bit = 1u << (cell & 31);
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
         }
     };
     // round 0 = the certain set: every pivot whose start passes the boundary test scans its whole 3x3
-    for (int k = lane; k < npiv; k += 64) {
+    for (int k = tid; k < npiv; k += NT) {
         const int pu = pivs[2 * k] + pt.dx2, pvv = pivs[2 * k + 1] + pt.dy2;
         if (!inside(pu, pvv)) continue;
         request9(pu - OCW, pvv - OCW);
@@ -457,18 +466,18 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
     auto evaluate = [&](const uint32_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
         for (int b0 = 0; b0 < cnt; b0 += kSumBatch) {
             const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
-            for (int r0 = 0; r0 < nb; r0 += C::CPR) {
-                const int slot = r0 + grp;
+            for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
+                const int slot = r0 + wave * C::CPR + grp;
                 const bool on = slot < nb;
                 const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00000101u;
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 Acc acc;
                 if (mode == M_FAST) {
-                    acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
+                    acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff);
                 } else if (mode == M_CHIPNULL) {
-                    acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
+                    acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, AT, toff);
                 } else {
-                    acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, MF, AT, MFT, toff);
+                    acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, AT, toff);
                 }
                 if (mode != M_GENERAL) { acc.n = pt.NV; acc.sx = pt.SX; acc.sxx = pt.SXX; }
                 if (on && l == 0) {
@@ -477,9 +486,9 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
                 }
             }
             __syncthreads();
-            if (lane < nb) {
-                const uint32_t *sp = sums + 6 * lane;
-                const uint32_t pk = ids[dir * (b0 + lane)];
+            if (tid < nb) {
+                const uint32_t *sp = sums + 6 * tid;
+                const uint32_t pk = ids[dir * (b0 + tid)];
                 nccv[pk >> 16] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
             }
             __syncthreads();
@@ -491,11 +500,12 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
     // cells the sequential state machine will ask for are evaluated in a few bulk batches.  Purely a
     // prefetch: it never touches `vis`; the result is decided by the exact replay (stage kSpecRounds).
     constexpr int kSpecRounds = 16;
+    const int kLookahead = p.lookahead;
     int stage = 0;
     int su = 0, sv = 0;
     bool alive = false;
     float smax = -2.0f;
-    if (lane < npiv) {
+    if (wave == 0 && lane < npiv) {
         su = pivs[2 * lane] + pt.dx2; sv = pivs[2 * lane + 1] + pt.dy2;
         alive = inside(su, sv);
     }
@@ -513,19 +523,22 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
 
     for (int guard = 0; guard <= pt.ncell + 16; guard++) {
         if (qcnt[3]) {                                   // NCC cache overflow: let the general kernel redo this point
-            if (lane == 0) p.ovf_list[atomicAdd(p.ovf_count, 1)] = gidx;
+            if (tid == 0) p.ovf_list[atomicAdd(p.ovf_count, 1)] = gidx;
             return;
         }
         {   // evaluate everything queued, then empty the queue (the only call site of `evaluate`)
             const int nA = qcnt[0], nB = qcnt[1];
             __syncthreads();
-            if (lane < 2) qcnt[lane] = 0;
+            if (tid < 2) qcnt[tid] = 0;
             evaluate(list, 1, nA, clean_mode);
             evaluate(list + lcap - 1, -1, nB, M_GENERAL);
             __syncthreads();
         }
         if (p.debug_stop == 4) return;
         MIMC3_STAMP(3)
+        // the sequential part runs on wave 0 only (lane k <-> pivot k); the other waves of the workgroup
+        // wait for its decision: 0 = cells were queued, evaluate and come back; 1 = the climb is finished
+        auto step = [&]() __attribute__((always_inline)) -> int {
         if (stage < kSpecRounds) {
             // each alive lane keeps scanning while its whole 3x3 is cached (values evaluated for other
             // pivots count too); when it runs into unknown cells it queues them, plus the 3x3 one step
@@ -552,25 +565,23 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
             }
             if (alive && nsc < kSpecRounds) {
                 request9(su - OCW, sv - OCW);
-                if ((ldu | ldv) != 0 && inside(su + ldu, sv + ldv)) request9(su + ldu - OCW, sv + ldv - OCW);
+                for (int la = 1; la <= kLookahead; la++)              // straight-line lookahead along the last move
+                    if ((ldu | ldv) != 0 && inside(su + la * ldu, sv + la * ldv)) request9(su + la * ldu - OCW, sv + la * ldv - OCW);
             }
-            __syncthreads();
             stage++;
             MIMC3_STAMP(4)
             const bool more = __any(alive && nsc < kSpecRounds);
-            if (more && qcnt[0] + qcnt[1] != 0) continue;          // evaluate the queued cells, then scan on
+            if (more && qcnt[0] + qcnt[1] != 0) return 0;          // evaluate the queued cells, then scan on
             replay_generic = (npiv > 64) || __any(alive);           // a climb longer than kSpecRounds scans: generic replay
             stage = kSpecRounds;
-            if (qcnt[0] + qcnt[1] != 0) continue;                   // (generic case) evaluate what was queued first
+            if (qcnt[0] + qcnt[1] != 0) return 0;                   // (generic case) evaluate what was queued first
         }
-        if (p.debug_stop == 5) return;
         if (!replay_generic) {
             // ---- exact replay from the recorded trajectories.  Every scan's move and running maximum
             //      depend only on NCC values (identical to the reference's compare sequence, :736-741);
             //      the visited state only decides HOW MANY scans of a pivot really happen (newncc != 0,
             //      :699) -- that part is sequential over pivots and is all that is done here.
             MIMC3_STAMP(5)
-            if (p.debug_stop == 8) return;
             int T = 0;                                   // lane k: number of scans pivot k really performs
             const bool regmask = (pt.csx <= 64 && pt.csy <= 64);
             // visited set in REGISTERS when it fits: lane r holds the 64-bit column mask of compact row r;
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
                 const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)fpos, bi);
                 peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
             }
-            break;
+            return 1;
         }
         // ---- exact hill climb (resumable), generic form: the reference's sequential loops ----------
         bool finished = false;
@@ -682,14 +693,19 @@ __global__ __launch_bounds__(64, (C::RF * C::GPR + C::TT <= 24) ? 4 : 2) void ma
             if (bv > nccmax) { nccmax = bv; du = bi / 3 - 1; dv = bi % 3 - 1; }
             pu += du; pvv += dv;
         }
-        if (finished) break;
+        return finished ? 1 : 0;
+            };
+        if (wave == 0) {
+            const int decision = step();
+            if (lane == 0) qcnt[9] = decision;
+        }
         __syncthreads();
+        if (qcnt[9]) break;
     }
-
     MIMC3_STAMP(3)
-    if (p.debug_stop == 6) { if (lane == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
+    if (p.debug_stop == 6) { if (tid == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
     // ---- 3x3 quadratic fit (:757-788) ----------------------------------------------------------
-    if (lane == 0) {
+    if (tid == 0) {
         float n9[9];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -748,8 +764,11 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     // pitch (dwords): written dwords + one zero dword, and the right-most cell's sliding read-ahead
     const int csx = Dx2 - 2 * C::OCW + 1;
     const int pw_a = ((3 + (Dx2 - 1) + 3) >> 2) + 1, pw_b = ((3 + csx - 2) >> 2) + C::GPR + 1;
-    a.lds_pw = 4 * (pw_a > pw_b ? pw_a : pw_b);
-    static const int slack = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 64;   // tests shrink it to force the overflow path
+    a.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
+    // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
+    // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
+    static const int slack_env = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 0;   // tests shrink it to force the overflow path
+    const int slack = slack_env ? slack_env : (max_npiv <= 20 ? 64 : 12 * max_npiv);
     int cap = 9 * max_npiv + slack;
     if (cap > cells) cap = cells;
     if (cap < 16) cap = 16;
@@ -762,7 +781,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     off = (off + 15) & ~(size_t)15; a.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
     off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
-    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 16;
+    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 64;
     off = (off + 15) & ~(size_t)15; a.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
     off = (off + 15) & ~(size_t)15;
     if (off > 160 * 1024) return hipErrorInvalidValue;
@@ -774,6 +793,8 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     }
     const unsigned nb = (unsigned)((a.N + 7) & ~7);
     static const int dbg = getenv("MIMC3_U8_DEBUG_STOP") ? atoi(getenv("MIMC3_U8_DEBUG_STOP")) : 0;
+    static const int look = getenv("MIMC3_U8_LOOKAHEAD") ? atoi(getenv("MIMC3_U8_LOOKAHEAD")) : 1;
+    a.lookahead = look;
     a.debug_stop = dbg;
     static unsigned long long *d_stats = nullptr;
     static const bool want_stats = getenv("MIMC3_U8_STATS") != nullptr;
@@ -785,7 +806,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     }
     a.stats = want_stats ? d_stats : nullptr;
     if (want_stats) (void)hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long) * (size_t)nb, stream);
-    hipLaunchKernelGGL(match_ncc_dlc_u8<C>, dim3(nb), dim3(64), off, stream, a);
+    hipLaunchKernelGGL(match_ncc_dlc_u8<C>, dim3(nb), dim3(C::NT), off, stream, a);
     if (want_stats) {
         (void)hipStreamSynchronize(stream);
         unsigned long long *hh = (unsigned long long *)malloc(8 * sizeof(unsigned long long) * (size_t)nb);
@@ -816,9 +837,10 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
     case 7: return launch_cfg<U8Cfg<7, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<U8Cfg<15, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<U8Cfg<16, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 30: return launch_cfg<U8Cfg<30, 32>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_cfg<U8Cfg<32, 32>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<U8Cfg<40, 64>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    // big chips: 4 waves share one point's LDS image (one cell per wave and round)
+    case 30: return launch_cfg<U8Cfg<30, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<U8Cfg<32, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<U8Cfg<40, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }
