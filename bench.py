@@ -45,8 +45,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
-    ap.add_argument("--path", default="auto", choices=["auto", "general"],
-                    help="auto: exact u8 kernel when the pair is 8-bit integral; general: force the f32/f64 kernel")
+    ap.add_argument("--path", default="auto", choices=["auto", "general", "f32"],
+                    help="auto: exact u8 kernel when the pair is 8-bit integral; f32: the register-tiled f32 kernel "
+                         "(what 16-bit / filtered imagery gets); general: force the fallback f32 kernel")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank matches its own lattice of the config's size (default); "
                          "strong: the config's points are sharded across ranks (BASELINE configs[2])")
@@ -162,6 +163,7 @@ def main():
             "vs_baseline": None,
             "dtype": ("u8 pixels, exact u32 dot4 sums, f64 NCC" if ctx.last_path() == "u8_exact"
                       else "f32 pixels, f32 products, f64 sums and NCC"),
+            "kernel_path": ctx.last_path(),
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points on rank 0 of {n_job} per step "
                                    f"({case.dimx}x{case.dimy}), ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), "
@@ -170,7 +172,7 @@ def main():
                        "parallelism": f"grid-point shard x{world}" + (", RCCL all-gather of [N,3]" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "match_ncc_dlc_u8" if ctx.last_path() == "u8_exact" else "match_ncc_dlc_f32",
+                         "kernel": {"u8_exact": "match_ncc_dlc_u8", "f32_tiled": "match_ncc_dlc_px<PxF32>"}.get(ctx.last_path(), "match_ncc_dlc_f32"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
         }

@@ -47,13 +47,15 @@ int mimc3_ctx_set_images(mimc3_ctx *ctx, const float *i0, const float *i1, int32
 /* Adopt device-resident images (no copy; caller keeps ownership, must outlive the context use). */
 int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i1, int32_t H, int32_t W);
 
-/* Kernel selection.  By default (mode 0) the library picks, per matcher call, the exact-integer
- * u8 kernel when BOTH resident images were proven (on the device, at set_images time) to hold only
- * integers in [0,255] -- the 8-bit TIFF case of GMA_float_load_tiff (GMA.c:288-298) -- and the chip
- * size is one of the instantiated ones (ocw 7, 15, 16, 30, 32, 40); otherwise the general f32/f64
- * kernel.  Both give results bit-identical to the reference on such data.  mode 1 forces the
- * general kernel (used by the parity tests to cover it on 8-bit inputs too).
- * mimc3_ctx_last_path: 0 = general f32/f64 kernel, 1 = exact u8 kernel, <0 = none yet. */
+/* Kernel selection.  By default (mode 0) the library picks, per matcher call:
+ *   1 = exact-integer u8 kernel when BOTH resident images were proven (on the device, at set_images
+ *       time) to hold only integers in [0,255] -- the 8-bit TIFF case of GMA_float_load_tiff
+ *       (GMA.c:288-298) -- and ocw is one of 7, 15, 16, 30, 32, 40;
+ *   2 = register-tiled f32 kernel (any f32 imagery) when ocw is one of 7, 15, 16;
+ *   0 = general f32 kernel (any ocw, any window size) otherwise.
+ * All three give results bit-identical to the reference on integral-DN data.  mode 1 forces kernel 0,
+ * mode 2 skips the u8 kernel (tests use them to cover every kernel on 8-bit inputs too).
+ * mimc3_ctx_last_path returns the kernel of the last call (<0 = none yet). */
 int mimc3_ctx_set_path(mimc3_ctx *ctx, int32_t mode);
 int mimc3_ctx_last_path(mimc3_ctx *ctx);
 

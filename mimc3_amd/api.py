@@ -196,11 +196,12 @@ class Context:
 
     # -- kernel selection ---------------------------------------------------------------------
     def set_path(self, mode):
-        """0 = auto (exact u8 kernel when the pair is 8-bit integral), 1 = force the general f32 kernel."""
-        _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1}.get(mode, mode)), "set_path")
+        """"auto" (0): u8 kernel when the pair is 8-bit integral, else the tiled f32 kernel, else the general
+        one; "general" (1): force the general f32 kernel; "f32" (2): like auto but never the u8 kernel."""
+        _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1, "f32": 2}.get(mode, mode)), "set_path")
 
     def last_path(self):
-        return {0: "general_f32", 1: "u8_exact"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
+        return {0: "general_f32", 1: "u8_exact", 2: "f32_tiled"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
 
     # -- timing -------------------------------------------------------------------------------
     def enable_timing(self, on=True):

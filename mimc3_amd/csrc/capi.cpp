@@ -54,6 +54,8 @@ struct mimc3_ctx {
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
+    DevBuf fpl0, fpl1;                  // zero-bordered f32 planes (register-tiled f32 kernel), built on first use
+    bool fplanes_ok = false;
     int32_t Wp = 0;
     bool u8_ok = false;                 // both images proven to be integers in [0,255]
     int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
@@ -102,7 +104,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
-    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release();
+    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fpl0.release(); c->fpl1.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -116,6 +118,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
 static int prepare_u8(mimc3_ctx *c)
 {
     c->u8_ok = false;
+    c->fplanes_ok = false;
     const int pad = mimc3::kU8Pad;
     c->Wp = (c->W + 2 * pad + 3) & ~3;
     const size_t bytes = (size_t)(c->H + 2 * pad) * c->Wp;
@@ -138,7 +141,7 @@ static int prepare_u8(mimc3_ctx *c)
 
 extern "C" int mimc3_ctx_set_path(mimc3_ctx *c, int32_t mode)
 {
-    if (!c || mode < 0 || mode > 1) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
+    if (!c || mode < 0 || mode > 2) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
     c->path_mode = mode;
     return 0;
 }
@@ -209,10 +212,11 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
     const int reach_u = max_abs_piv_u + (off_u < 0 ? -off_u : off_u), reach_v = max_abs_piv_v + (off_v < 0 ? -off_v : off_v);
     hipError_t e;
-    if (c->path_mode == 0 && c->u8_ok && mimc3::match_u8_supported(ocw, reach_u, reach_v)) {
+    const bool want_u8 = c->path_mode == 0 && c->u8_ok && mimc3::match_u8_supported(ocw, reach_u, reach_v);
+    const bool want_f32x = !want_u8 && c->path_mode != 1 && mimc3::match_f32x_supported(ocw, reach_u, reach_v);
+    if (want_u8 || want_f32x) {
         mimc3::MatchU8Args u{};
-        u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
-        u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W;
+        u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W; u.thr = a.thr;
         u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
         u.piv_uv = d_piv_uv; u.piv_off = d_piv_off; u.ocw = ocw; u.swap = swap ? 1 : 0; u.out = d_out;
         // points whose per-point NCC cache overflows (very long climbs) are appended to a device list and
@@ -221,13 +225,30 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         HIP_TRY(hipMemsetAsync(c->ovf.p, 0, sizeof(int32_t), s));
         u.ovf_count = static_cast<int32_t *>(c->ovf.p);
         u.ovf_list = u.ovf_count + 1;
-        e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+        if (want_u8) {
+            u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
+            e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+            c->last_path = 1;
+        } else {
+            if (!c->fplanes_ok) {      // zero-bordered f32 copies of the pair, once per image pair
+                const size_t bytes = sizeof(float) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
+                HIP_TRY(c->fpl0.reserve(bytes));
+                HIP_TRY(c->fpl1.reserve(bytes));
+                HIP_TRY(hipMemsetAsync(c->fpl0.p, 0, bytes, s));
+                HIP_TRY(hipMemsetAsync(c->fpl1.p, 0, bytes, s));
+                HIP_TRY(mimc3::launch_prep_f32(c->d_i0, c->H, c->W, static_cast<float *>(c->fpl0.p), c->Wp, mimc3::kU8Pad, s));
+                HIP_TRY(mimc3::launch_prep_f32(c->d_i1, c->H, c->W, static_cast<float *>(c->fpl1.p), c->Wp, mimc3::kU8Pad, s));
+                c->fplanes_ok = true;
+            }
+            u.p0 = static_cast<const unsigned char *>(c->fpl0.p); u.p1 = static_cast<const unsigned char *>(c->fpl1.p);
+            e = mimc3::launch_match_f32x(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+            c->last_path = 2;
+        }
         if (e == hipSuccess) {
             a.point_count = u.ovf_count;
             a.point_list = u.ovf_list;
             e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
         }
-        c->last_path = 1;
     } else {
         e = mimc3::launch_match_f32(a, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
         c->last_path = 0;

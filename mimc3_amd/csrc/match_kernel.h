@@ -28,9 +28,10 @@ struct MatchArgs {
 // ---- exact-integer path for 8-bit imagery (match_u8_kernel.hip) -------------------------------
 constexpr int kU8Pad = 256;      // zero border (pixels) around the u8 planes; multiple of 4
 
-struct MatchU8Args {
-    const unsigned char *p0, *p1;   // zero-bordered u8 planes of i0, i1: pixel (u,v) at [(v+pad)*Wp + u+pad]
-    int32_t Wp, pad;                // plane pitch (bytes, % 4 == 0) and border
+struct MatchU8Args {                // arguments of the register-tiled kernel family (match_px_kernel.hip)
+    const unsigned char *p0, *p1;   // zero-bordered planes of i0, i1 (u8 or f32 pixels): pixel (u,v) at [(v+pad)*Wp + u+pad]
+    int32_t Wp, pad;                // plane pitch (PIXELS; a whole number of dwords) and border
+    float thr;                      // smallest f32 whose f64 value is >= MIN_DN (f32 policy)
     int32_t H, W;
     const double *xyuvav;
     int32_t N;
@@ -53,6 +54,10 @@ struct MatchU8Args {
 hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, int Wp, int pad, int *d_flag, hipStream_t s);
 // instantiated chip sizes and border reach (|last pivot| + |CP offset| must fit in the border)
 bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v);
+// same kernel family on zero-bordered f32 planes (any f32 imagery; small chips only)
+hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp, int pad, hipStream_t s);
+bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v);
+hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 
 // max_abs_u/v: max over points of |last pivot| per axis; max_npiv: max pivots per point.

@@ -1,26 +1,25 @@
-// match_u8_kernel.hip -- DLC/NCC matcher for gfx950, exact-integer path for 8-bit imagery.
+// match_px_kernel.hip -- DLC/NCC matcher for gfx950, register-tiled kernel family.
 //
-// Same contract as match_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842) but for image
-// pairs whose pixels are all integers in [0,255] (what GMA_float_load_tiff yields for an 8-bit
-// TIFF, GMA.c:288-310).  For such data every running sum of the reference's NCC loop
-// (MIMC_module.c:719-733: n, sx, sy, sxx, syy, sxy; f32 products, f64 accumulation) is an exact
-// integer < 2^31, so the sums are computed with v_dot4_u32_u8 on packed bytes and converted to
-// f64 only for the final formula (:734) -- bit-identical to the reference, ~4 MACs per VALU op.
+// Same contract as match_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842).  One kernel
+// template, two pixel policies:
+//   PxU8   image pairs whose pixels are all integers in [0,255] (what GMA_float_load_tiff yields for
+//          an 8-bit TIFF, GMA.c:288-310).  Every running sum of the reference's NCC loop
+//          (MIMC_module.c:719-733: n, sx, sy, sxx, syy, sxy; f32 products, f64 accumulation) is then an
+//          exact integer < 2^31: v_dot4_u32_u8 on packed bytes, f64 only for the final formula (:734).
+//   PxF32  any f32 imagery (16-bit DN, filtered images, floats): f32 products, f64 accumulation in
+//          registers, exactly the reference's arithmetic up to the summation order.
 //
-// Layout / decomposition (one wave64 = one grid point, no workgroup barriers):
-//   * the images live in HBM as zero-bordered u8 planes (border >= kU8Pad px, pitch % 4 == 0), built
-//     once per image pair by prep_u8_plane (which also PROVES the pair is 8-bit integral);
-//   * the DLC window is staged into LDS as aligned dwords (keeps the global byte phase `sh`);
-//     null pixels are DN == 0, so masks are derived from the bytes themselves;
-//   * the chip lives in REGISTERS: each of the 64/LPC lane groups holds the whole chip, lane l of a
-//     group owns rows l, l+LPC, ... as packed dwords (+ a few single-group "tail" tasks);
-//   * one evaluation round computes 64/LPC NCC cells at once: a lane slides over the aligned window
-//     dwords of its row, v_alignbyte_b32 extracts the 4 window bytes under each chip group, dot4
-//     accumulates; the LPC lanes of a cell are reduced with DPP row operations;
-//   * FAST mode (no null pixel in chip or window): n, sx, sxx are per-point constants -> 3 dot4 per
-//     4 pixels; otherwise GENERAL mode: 6 dot4 + byte-mask algebra per 4 pixels;
-//   * the hill climb (MIMC_module.c:691-753) runs on the same wave as a resumable state machine over
-//     the cached NCC values, exactly as in match_kernel.hip (first-wins arg-max, observable laziness).
+// Layout / decomposition (one workgroup of NW wave64 = one grid point):
+//   * the images live in HBM as zero-bordered planes (border >= kU8Pad px, pitch a whole number of
+//     dwords), built once per image pair (prep_*_plane; the u8 one also PROVES the pair is 8-bit);
+//   * the DLC window is staged into LDS as aligned dwords (keeps the global pixel phase `sh`);
+//   * the chip lives in REGISTERS: each of the 64/LPC lane groups of a wave holds the whole chip,
+//     lane l of a group owns rows l, l+LPC, ... as dwords (+ a few single-dword "tail" tasks);
+//   * one evaluation round computes NW*64/LPC NCC cells: a lane slides over the aligned window dwords
+//     of its row (v_alignbyte_b32 when a dword holds several pixels), accumulates, and the LPC lanes
+//     of a cell are reduced with DPP row operations;
+//   * per-cell modes FAST / CHIPNULL / GENERAL (null handling), slot-mapped NCC cache, speculative
+//     parallel climb + exact replay of the reference's sequential hill climb (:691-753): see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -71,17 +70,150 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 #undef MIMC3_ARGMAX_STEP
 }
 
-template <int OCW_, int LPC_, int NW_ = 1>
-struct U8Cfg {
+// Evaluation modes, chosen PER CELL (the cells of a round share one mode):
+//   FAST     chip has no null and the cell's box of the window has no null : n, sx, sxx constant
+//   CHIPNULL chip has nulls, box has none                                    : n, sx, sxx constant
+//   GENERAL  the box contains null window pixels                             : all six sums
+enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2 };
+
+template <class S> struct AccT { uint32_t n; S sx, sy, sxx, syy, sxy; };
+
+__device__ __forceinline__ double dpp_add_f64(double x, int ctrl_sel)
+{
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    int olo, ohi;
+    switch (ctrl_sel) {
+    case 0: olo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: olo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: olo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: olo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
+    }
+    return x + __longlong_as_double(((long long)ohi << 32) | (unsigned int)olo);
+}
+
+// ---- pixel policy: 8-bit integral imagery, 4 pixels per dword, exact integer sums --------------------
+struct PxU8 {
+    static constexpr int BPP = 1, G = 4, LOG2G = 2;
+    typedef uint32_t Sum;
+    static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
+    __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
+    __device__ static __forceinline__ int npx(uint32_t m) { return __popc(m & 0x01010101u); }
+    // "x < MIN_DN" (:622,:631) and "not (x >= MIN_DN)" (:723) coincide for integers: null <=> DN == 0
+    __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float) { return npx(keep) - __popc(nz80(v) >> 7); }
+    __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return nbad(v, keep, thr); }
+    __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float) { return a; }     // nulls are already 0
+    __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a) { sx = dot4(a, 0x01010101u, sx); sxx = dot4(a, a, sxx); }
+    template <int MODE>
+    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t pad01, uint32_t padff, bool static_pad, uint32_t bw, float)
+    {
+        // byte mask of the chip group: 0xFF where the chip pixel is valid (null pixels and the pad bytes of the
+        // last group are 0 in `a`), derived on the fly -- keeping it in registers would cost a second chip image
+        const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
+        if (MODE == M_FAST) {
+            const uint32_t m01 = static_pad ? pad01 : (mf & 0x01010101u);
+            const uint32_t mff = static_pad ? padff : mf;
+            acc.sy = dot4(m01, bw, acc.sy);
+            acc.syy = dot4((static_pad && padff == 0xffffffffu) ? bw : (bw & mff), bw, acc.syy);
+            acc.sxy = dot4(a, bw, acc.sxy);
+        } else if (MODE == M_CHIPNULL) {
+            acc.sy = dot4(mf & 0x01010101u, bw, acc.sy);
+            acc.syy = dot4(bw & mf, bw, acc.syy);
+            acc.sxy = dot4(a, bw, acc.sxy);
+        } else {
+            const uint32_t t = nz80(bw);
+            const uint32_t mb01 = t >> 7, mbff = ff_from80(t);
+            const uint32_t ma01 = mf & 0x01010101u;
+            acc.n = dot4(ma01, mb01, acc.n);
+            acc.sx = dot4(a, mb01, acc.sx);          // a == 0 where the chip pixel is null
+            acc.sy = dot4(ma01, bw, acc.sy);         // bw == 0 where the window pixel is null
+            acc.sxy = dot4(a, bw, acc.sxy);
+            acc.sxx = dot4(a & mbff, a, acc.sxx);
+            acc.syy = dot4(bw & mf, bw, acc.syy);
+        }
+    }
+    template <int LPC> __device__ static __forceinline__ Sum gsum(Sum v) { return group_sum<LPC>(v); }
+    typedef uint32_t Store;                                    // how a reduced sum is parked in LDS
+    __device__ static __forceinline__ Store bits(Sum v) { return v; }
+    // NCC from exact integer sums (MIMC_module.c:734), f64, no contraction
+    __device__ static __forceinline__ float ncc(const Store *sp)
+    {
+        const double dn = (double)sp[0], dsx = (double)sp[1], dsy = (double)sp[2];
+        const double num = dn * (double)sp[5] - dsx * dsy;
+        const double den = sqrt((dn * (double)sp[3] - dsx * dsx) * (dn * (double)sp[4] - dsy * dsy));
+        return (float)(num / den);
+    }
+};
+
+// ---- pixel policy: arbitrary f32 imagery, 1 pixel per dword, f32 products + f64 sums (:726-730) ------
+struct PxF32 {
+    static constexpr int BPP = 4, G = 1, LOG2G = 0;
+    typedef double Sum;
+    static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
+    __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
+    __device__ static __forceinline__ int npx(uint32_t m) { return m ? 1 : 0; }
+    __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float thr) { return (keep && __uint_as_float(v) < thr) ? 1 : 0; }       // :622
+    __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return (keep && !(__uint_as_float(v) >= thr)) ? 1 : 0; }  // :723 (NaN too)
+    __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float thr) { return (__uint_as_float(a) >= thr) ? a : 0u; }  // excluded chip pixels -> 0.0
+    __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a)
+    {
+        const float f = __uint_as_float(a);
+        sx += (double)f; sxx += (double)(f * f);
+    }
+    template <int MODE>
+    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t, uint32_t, bool, uint32_t bu, float thr)
+    {
+        const float a = __uint_as_float(au), b = __uint_as_float(bu);   // a is 0.0 for excluded chip pixels and unused slots
+        if (MODE == M_FAST) {
+            const bool on = au != 0u;                                    // unused tail slots only (the chip has no null here)
+            const float bm = on ? b : 0.0f;
+            acc.sy += (double)bm; acc.syy += (double)(bm * bm); acc.sxy += (double)(on ? a * b : 0.0f);
+        } else if (MODE == M_CHIPNULL) {
+            const bool on = au != 0u;
+            const float bm = on ? b : 0.0f;
+            acc.sy += (double)bm; acc.syy += (double)(bm * bm); acc.sxy += (double)(on ? a * b : 0.0f);
+        } else {
+            const bool ok = (au != 0u) && (b >= thr);                     // null exclusion (:723)
+            const float a2 = ok ? a : 0.0f, b2 = ok ? b : 0.0f;
+            acc.n += ok ? 1u : 0u;
+            acc.sx += (double)a2; acc.sy += (double)b2;
+            acc.sxx += (double)(a2 * a2); acc.syy += (double)(b2 * b2); acc.sxy += (double)(a2 * b2);
+        }
+    }
+    template <int LPC> __device__ static __forceinline__ Sum gsum(Sum v)
+    {
+        v = dpp_add_f64(v, 0); v = dpp_add_f64(v, 1); v = dpp_add_f64(v, 2); v = dpp_add_f64(v, 3);
+        if (LPC >= 32) v += __shfl_xor(v, 16, 64);
+        if (LPC >= 64) v += __shfl_xor(v, 32, 64);
+        return v;
+    }
+    typedef unsigned long long Store;
+    __device__ static __forceinline__ Store bits(Sum v) { return (unsigned long long)__double_as_longlong(v); }
+    __device__ static __forceinline__ float ncc(const Store *sp)
+    {
+        const double dn = (double)(uint32_t)sp[0];
+        const double sx = __longlong_as_double((long long)sp[1]), sy = __longlong_as_double((long long)sp[2]);
+        const double sxx = __longlong_as_double((long long)sp[3]), syy = __longlong_as_double((long long)sp[4]);
+        const double sxy = __longlong_as_double((long long)sp[5]);
+        const double num = dn * sxy - sx * sy;
+        const double den = sqrt((dn * sxx - sx * sx) * (dn * syy - sy * sy));
+        return (float)(num / den);
+    }
+};
+
+template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2>
+struct PxCfg {
+    typedef P_ P;
+    static constexpr int MINW = MINW_;                       // occupancy target, waves per SIMD
     static constexpr int OCW = OCW_, LPC = LPC_;
     static constexpr int NW = NW_, NT = 64 * NW_;            // waves / threads per grid point (one workgroup)
     static constexpr int CW = 2 * OCW + 1, NPX = CW * CW;
-    static constexpr int GPR = (CW + 3) / 4;                 // packed dwords per chip row
+    static constexpr int GPR = (CW + P::G - 1) / P::G;       // dwords per chip row
     static constexpr int RF = CW / LPC;                      // full rounds: rows l + LPC*i
     static constexpr int REM = CW - RF * LPC;                // leftover rows, split into single-group tasks
     static constexpr int TT = (REM * GPR + LPC - 1) / LPC;   // tail tasks per lane
-    static constexpr int LASTN = CW - 4 * (GPR - 1);         // valid bytes of the last group (1..4)
-    static constexpr uint32_t LASTFF = LASTN == 4 ? 0xffffffffu : ((1u << (8 * LASTN)) - 1u);
+    static constexpr int LASTN = CW - P::G * (GPR - 1);      // valid pixels of the last dword of a row (1..G)
+    static constexpr uint32_t LASTFF = P::lowmask_c(LASTN);
     static constexpr uint32_t LAST01 = LASTFF & 0x01010101u;
     static constexpr int CPR = 64 / LPC;                     // cells per evaluation round
 };
@@ -90,93 +222,48 @@ struct U8Point {
     int dx2, dy2, Dx2, Dy2, csx, csy, ncell;
     int sh;            // byte phase of window column 0 inside its aligned dword
     int PW;            // LDS window pitch, bytes
-    uint32_t NV, SX, SXX;   // chip constants: valid pixels, sum a, sum a^2 (nulls are 0 so they drop out)
+    float thr;         // smallest f32 whose f64 value is >= MIN_DN
 };
-
-// Evaluation modes, chosen PER CELL (the 64/LPC cells of a round share one mode):
-//   FAST     chip has no null and the cell's box of the window has no null : n, sx, sxx constant
-//   CHIPNULL chip has nulls, box has none                                    : n, sx, sxx constant
-//   GENERAL  the box contains null window pixels                             : all six sums
-enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2 };
-
-struct Acc { uint32_t n, sx, sy, sxx, syy, sxy; };
-
-template <int MODE>
-__device__ __forceinline__ void task(Acc &acc, uint32_t a, uint32_t pad01, uint32_t padff, bool static_pad, uint32_t bw)
-{
-    // byte mask of the chip group: 0xFF where the chip pixel is valid (null pixels and the pad bytes of the
-    // last group are 0 in `a`), derived on the fly -- keeping it in registers would cost a second chip image
-    const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
-    if (MODE == M_FAST) {
-        // mf is exactly the pad mask here; for the unrolled full rows it is a compile-time constant
-        const uint32_t m01 = static_pad ? pad01 : (mf & 0x01010101u);
-        const uint32_t mff = static_pad ? padff : mf;
-        acc.sy = dot4(m01, bw, acc.sy);
-        acc.syy = dot4((static_pad && padff == 0xffffffffu) ? bw : (bw & mff), bw, acc.syy);
-        acc.sxy = dot4(a, bw, acc.sxy);
-    } else if (MODE == M_CHIPNULL) {
-        acc.sy = dot4(mf & 0x01010101u, bw, acc.sy);
-        acc.syy = dot4(bw & mf, bw, acc.syy);
-        acc.sxy = dot4(a, bw, acc.sxy);
-    } else {
-        const uint32_t t = nz80(bw);
-        const uint32_t mb01 = t >> 7, mbff = ff_from80(t);
-        const uint32_t ma01 = mf & 0x01010101u;
-        acc.n = dot4(ma01, mb01, acc.n);
-        acc.sx = dot4(a, mb01, acc.sx);          // a == 0 where the chip pixel is null
-        acc.sy = dot4(ma01, bw, acc.sy);         // bw == 0 where the window pixel is null
-        acc.sxy = dot4(a, bw, acc.sxy);
-        acc.sxx = dot4(a & mbff, a, acc.sxx);
-        acc.syy = dot4(bw & mf, bw, acc.syy);
-    }
-}
 
 // One evaluation round: lane group g (LPC lanes) evaluates the cell whose chip origin in window
 // coordinates is (cx, cy) (== compact cell coordinates).  Returns group-reduced sums in every lane.
 template <class C, int MODE>
-__device__ __forceinline__ Acc eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
+__device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
                                           const int (&toff)[C::TT > 0 ? C::TT : 1])
 {
-    Acc acc{0, 0, 0, 0, 0, 0};
-    const int X = pt.sh + cx;
-    const uint32_t s = (uint32_t)(X & 3);
-    const unsigned char *base = W + cy * pt.PW + (X & ~3);
+    typedef typename C::P P;
+    AccT<typename P::Sum> acc{0, 0, 0, 0, 0, 0};
+    const int X = pt.sh + cx;                                       // pixel offset of the box inside the LDS row
+    const uint32_t s = (uint32_t)((X & (P::G - 1)) * P::BPP);       // byte phase inside the first dword
+    const unsigned char *base = W + cy * pt.PW + 4 * (X >> P::LOG2G);
+    constexpr int NLD = C::GPR + (P::G > 1 ? 1 : 0);                // dwords a row task reads
 #pragma unroll
     for (int i = 0; i < C::RF; i++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + (l + C::LPC * i) * pt.PW);
-        uint32_t w[C::GPR + 1];
+        uint32_t w[NLD];
 #pragma unroll
-        for (int j = 0; j <= C::GPR; j++) w[j] = rp[j];
+        for (int j = 0; j < NLD; j++) w[j] = rp[j];
 #pragma unroll
         for (int j = 0; j < C::GPR; j++) {
-            const uint32_t bw = alignb(w[j + 1], w[j], s);
+            const uint32_t bw = (P::G > 1) ? alignb(w[j + (P::G > 1 ? 1 : 0)], w[j], s) : w[j];
             const uint32_t p01 = (j == C::GPR - 1) ? C::LAST01 : 0x01010101u;
             const uint32_t pff = (j == C::GPR - 1) ? C::LASTFF : 0xffffffffu;
-            task<MODE>(acc, A[i][j], p01, pff, true, bw);
+            P::template task<MODE>(acc, A[i][j], p01, pff, true, bw, pt.thr);
         }
     }
 #pragma unroll
     for (int k = 0; k < C::TT; k++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + toff[k]);
-        const uint32_t bw = alignb(rp[1], rp[0], s);
-        task<MODE>(acc, AT[k], 0, 0, false, bw);   // tail tasks: pad/null masks come from the bytes of AT[k]
+        const uint32_t bw = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], s) : rp[0];
+        P::template task<MODE>(acc, AT[k], 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from AT[k] itself
     }
-    acc.sy = group_sum<C::LPC>(acc.sy); acc.syy = group_sum<C::LPC>(acc.syy); acc.sxy = group_sum<C::LPC>(acc.sxy);
+    acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE == M_GENERAL) {
-        acc.n = group_sum<C::LPC>(acc.n); acc.sx = group_sum<C::LPC>(acc.sx); acc.sxx = group_sum<C::LPC>(acc.sxx);
+        acc.n = group_sum<C::LPC>(acc.n); acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx);
     }
     return acc;
-}
-
-// NCC from exact integer sums (MIMC_module.c:734), f64, no contraction
-__device__ __forceinline__ float ncc_from_sums(uint32_t n, uint32_t sx, uint32_t sy, uint32_t sxx, uint32_t syy, uint32_t sxy)
-{
-    const double dn = (double)n, dsx = (double)sx, dsy = (double)sy;
-    const double num = dn * (double)sxy - dsx * dsy;
-    const double den = sqrt((dn * (double)sxx - dsx * dsx) * (dn * (double)syy - dsy * dsy));
-    return (float)(num / den);
 }
 
 static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in LDS before the f64 finish
@@ -188,10 +275,11 @@ static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in
         t_prev = t_now;                                                                        \
     }
 
-// occupancy target: 4 waves per SIMD (<= 128 VGPRs) for the chips whose register image allows it
 template <class C>
-__global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void match_ncc_dlc_u8(MatchU8Args p)
+__global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p)
 {
+    typedef typename C::P P;
+    typedef typename P::Sum Sum;
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,7 +315,8 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
     pt.PW = p.lds_pw;
     const int wu0 = u0 + p.off_u - pt.dx2 + PAD;     // plane column of window column 0
     const int wv0 = v0 + p.off_v - pt.dy2 + PAD;     // plane row of window row 0
-    pt.sh = wu0 & 3;
+    pt.sh = wu0 & (P::G - 1);                        // pixel phase of window column 0 inside its aligned dword
+    pt.thr = p.thr;
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
@@ -238,7 +327,8 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
     uint32_t *reqb = reinterpret_cast<uint32_t *>(smem + p.lds_off_req);  // requested bits [ncell]
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits, rows padded to words
     uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // packed cells (slot<<16|cy<<8|cx): clean boxes from the front, dirty from the back
-    uint32_t *sums = reinterpret_cast<uint32_t *>(smem + p.lds_off_sums); // [kSumBatch][6]
+    typedef typename P::Store Store;
+    Store *sums = reinterpret_cast<Store *>(smem + p.lds_off_sums);        // [kSumBatch][6] reduced sums
     int32_t *pivs = reinterpret_cast<int32_t *>(smem + p.lds_off_piv);    // [npiv][2]
     const int lcap = p.lds_list_cap, cap = p.cache_cap;
     const bool map16 = p.map_u16 != 0;
@@ -254,7 +344,7 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
     for (int i = tid; i < 2 * npiv; i += NT) pivs[i] = pv_g[i];
     // control words: [0] clean queued, [1] dirty queued, [2] cache slots used, [3] cache overflow,
     // [4] null pixels in the window, [5..8] their bounding box (x0,x1,y0,y1), [9] driver decision
-    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);
+    int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // behind the sums
     if (tid < 16) qcnt[tid] = (tid == 5 || tid == 7) ? (1 << 20) : ((tid == 6 || tid == 8) ? -1 : 0);
     __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
@@ -264,18 +354,18 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
     };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
-    int bad_win = 0;
-    int nbx0 = 1 << 20, nbx1 = -1, nby0 = 1 << 20, nby1 = -1;   // bounding box of null pixels (window coords, dword-granular in x)
+    int bad_win = 0, exc_win = 0;                            // "x < MIN_DN" count (:631) / pixels the NCC loop skips (:723)
+    int nbx0 = 1 << 20, nbx1 = -1, nby0 = 1 << 20, nby1 = -1;   // bounding box of the skipped pixels (window coords, dword-granular in x)
     {
         const int wcols = 2 * pt.dx2, wrows = 2 * pt.dy2;                 // written area (:869-886)
-        const int nd = (pt.sh + wcols + 3) >> 2;                          // aligned dwords per row
+        const int nd = (pt.sh + wcols + P::G - 1) >> P::LOG2G;            // aligned dwords per row
         const uint32_t inv = (uint32_t)(0xffffffffu / (uint32_t)nd) + 1u; // exact idx/nd for idx*nd < 2^32
         const int tot = wrows * nd;
-        const int lastb = (pt.sh + wcols) & 3;                            // valid bytes in the last dword (0 = all)
-        const uint32_t first_ff = 0xffffffffu << (8 * pt.sh);
-        const uint32_t last_ff = lastb ? ((1u << (8 * lastb)) - 1u) : 0xffffffffu;
-        const uint32_t *gbase = reinterpret_cast<const uint32_t *>(win_pl + (size_t)wv0 * Wp + (wu0 & ~3));
-        const int gpitch = Wp >> 2;
+        const int lastp = (pt.sh + wcols) & (P::G - 1);                   // valid pixels in the last dword (0 = all)
+        const uint32_t first_ff = ~P::lowmask(pt.sh);
+        const uint32_t last_ff = lastp ? P::lowmask(lastp) : 0xffffffffu;
+        const uint32_t *gbase = reinterpret_cast<const uint32_t *>(win_pl + ((size_t)wv0 * Wp + (wu0 - pt.sh)) * P::BPP);
+        const int gpitch = (Wp * P::BPP) >> 2;
         for (int idx = tid; idx < tot; idx += NT) {
             const int r = (int)__umulhi((uint32_t)idx, inv);
             const int c = idx - r * nd;
@@ -283,13 +373,14 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
             uint32_t keep = 0xffffffffu;
             if (c == 0) keep &= first_ff;
             if (c == nd - 1) keep &= last_ff;
-            v &= keep;                                                    // bytes outside the written columns -> 0 (covers T4 column)
+            v &= keep;                                                    // pixels outside the written columns -> 0 (covers T4 column)
             *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = v;
-            const int nz = __popc(keep & 0x01010101u) - __popc((nz80(v) >> 7));
-            bad_win += nz;
+            bad_win += P::nbad(v, keep, pt.thr);
+            const int nz = P::nexcl(v, keep, pt.thr);
+            exc_win += nz;
             if (nz) {
-                const int x0 = 4 * c - pt.sh;
-                nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + 3); nby0 = min(nby0, r); nby1 = max(nby1, r);
+                const int x0 = P::G * c - pt.sh;
+                nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); nby0 = min(nby0, r); nby1 = max(nby1, r);
             }
         }
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
@@ -298,7 +389,7 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
         for (int c = tid; c < ndz; c += NT) *reinterpret_cast<uint32_t *>(W + wrows * pt.PW + 4 * c) = 0u;
         for (int r = tid; r < wrows; r += NT)
             for (int c = nd; c < ndz; c++) *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = 0u;
-        bad_win = wave_sum_i(bad_win);
+        bad_win = wave_sum_i(bad_win); exc_win = wave_sum_i(exc_win);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             nbx0 = min(nbx0, __shfl_xor(nbx0, o, 64)); nbx1 = max(nbx1, __shfl_xor(nbx1, o, 64));
@@ -306,45 +397,46 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
         }
         if (NW > 1) {                                        // combine the waves' partial results through LDS
             if (lane == 0) {
-                atomicAdd(&qcnt[4], bad_win);
+                atomicAdd(&qcnt[4], bad_win); atomicAdd(&qcnt[10], exc_win);
                 atomicMin(&qcnt[5], nbx0); atomicMax(&qcnt[6], nbx1); atomicMin(&qcnt[7], nby0); atomicMax(&qcnt[8], nby1);
             }
             __syncthreads();
-            bad_win = qcnt[4]; nbx0 = qcnt[5]; nbx1 = qcnt[6]; nby0 = qcnt[7]; nby1 = qcnt[8];
+            bad_win = qcnt[4]; exc_win = qcnt[10]; nbx0 = qcnt[5]; nbx1 = qcnt[6]; nby0 = qcnt[7]; nby1 = qcnt[8];
         }
     }
     if (p.debug_stop == 1) return;
     MIMC3_STAMP(0)
-    const bool win_clean = (bad_win == 0);                   // no null inside the written area
+    const bool win_clean = (exc_win == 0);                   // nothing the NCC loop would skip inside the written area
     bad_win += pt.Dx2 + pt.Dy2 - 1;                          // + the never-written last row and column
 
     // ---- chip -> registers (a4): every lane group holds the whole chip --------------------------
     constexpr int RFA = C::RF > 0 ? C::RF : 1, TTA = C::TT > 0 ? C::TT : 1;
     uint32_t A[RFA][GPR], AT[TTA];
     int toff[TTA];
-    int bad_chip = 0;
-    uint32_t SX = 0, SXX = 0;
+    int bad_chip = 0, exc_chip = 0;
+    Sum SX = 0, SXX = 0;
     {
         const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
-        const uint32_t sa = (uint32_t)(cu0 & 3);
-        const uint32_t *gbase = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 & ~3));
-        const int gpitch = Wp >> 2;
+        const int sap = cu0 & (P::G - 1);
+        const uint32_t sa = (uint32_t)(sap * P::BPP);
+        const uint32_t *gbase = reinterpret_cast<const uint32_t *>(chip_pl + ((size_t)cv0 * Wp + (cu0 - sap)) * P::BPP);
+        const int gpitch = (Wp * P::BPP) >> 2;
+        constexpr int NLD = GPR + (P::G > 1 ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < C::RF; i++) {
             const uint32_t *rp = gbase + (size_t)(l + C::LPC * i) * gpitch;
-            uint32_t g[GPR + 1];
+            uint32_t g[NLD];
 #pragma unroll
-            for (int j = 0; j <= GPR; j++) g[j] = rp[j];
+            for (int j = 0; j < NLD; j++) g[j] = rp[j];
 #pragma unroll
             for (int j = 0; j < GPR; j++) {
-                uint32_t a = alignb(g[j + 1], g[j], sa);
+                uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
                 const uint32_t pff = (j == GPR - 1) ? C::LASTFF : 0xffffffffu;
                 a &= pff;
+                bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
+                a = P::sanitize(a, pt.thr);
                 A[i][j] = a;
-                const uint32_t t = nz80(a);
-                bad_chip += __popc(pff & 0x01010101u) - __popc(t >> 7);
-                SX = dot4(a, 0x01010101u, SX);
-                SXX = dot4(a, a, SXX);
+                P::chip_acc(SX, SXX, a);
             }
         }
 #pragma unroll
@@ -353,23 +445,22 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
             const bool on = tt < C::REM * GPR;
             const int rr = C::RF * C::LPC + (on ? tt / GPR : 0), j = on ? tt % GPR : 0;
             const uint32_t *rp = gbase + (size_t)rr * gpitch + j;
-            uint32_t a = alignb(rp[1], rp[0], sa);
+            uint32_t a = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], sa) : rp[0];
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
+            bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
+            a = P::sanitize(a, pt.thr);
             AT[k] = a;
-            const uint32_t t = nz80(a);
             toff[k] = rr * pt.PW + 4 * j;
-            bad_chip += __popc(pff & 0x01010101u) - __popc(t >> 7);
-            SX = dot4(a, 0x01010101u, SX);
-            SXX = dot4(a, a, SXX);
+            P::chip_acc(SX, SXX, a);
         }
-        bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip);
-        SX = group_sum<C::LPC>(SX); SXX = group_sum<C::LPC>(SXX);
+        bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
+        SX = P::template gsum<C::LPC>(SX); SXX = P::template gsum<C::LPC>(SXX);
     }
-    pt.SX = SX; pt.SXX = SXX; pt.NV = (uint32_t)(C::NPX - bad_chip);
-    const int clean_mode = (bad_chip == 0) ? M_FAST : M_CHIPNULL;
+    const uint32_t NV = (uint32_t)(C::NPX - exc_chip);       // chip pixels that take part: n, sx, sxx are constants when the box is clean
+    const int clean_mode = (exc_chip == 0) ? M_FAST : M_CHIPNULL;
     MIMC3_STAMP(1)
-    if (p.debug_stop == 2) { if (tid == 0) p.out[3 * (size_t)gidx] = (float)(SX + SXX + bad_chip + A[0][0] + AT[0]); return; }
+    if (p.debug_stop == 2) { if (tid == 0) p.out[3 * (size_t)gidx] = (float)((uint32_t)P::bits(SX) + (uint32_t)P::bits(SXX) + bad_chip + A[0][0] + AT[0]); return; }
     __syncthreads();   // single-wave workgroup: orders the LDS stores above before the reads below
 
     // ---- validity (a6, :635) --------------------------------------------------------------------
@@ -471,7 +562,7 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
                 const bool on = slot < nb;
                 const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00000101u;
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
-                Acc acc;
+                AccT<Sum> acc;
                 if (mode == M_FAST) {
                     acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff);
                 } else if (mode == M_CHIPNULL) {
@@ -479,17 +570,16 @@ __global__ __launch_bounds__(C::NT, (C::RF * C::GPR + C::TT <= 28) ? 4 : 2) void
                 } else {
                     acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, AT, toff);
                 }
-                if (mode != M_GENERAL) { acc.n = pt.NV; acc.sx = pt.SX; acc.sxx = pt.SXX; }
+                if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
                 if (on && l == 0) {
-                    uint32_t *sp = sums + 6 * slot;
-                    sp[0] = acc.n; sp[1] = acc.sx; sp[2] = acc.sy; sp[3] = acc.sxx; sp[4] = acc.syy; sp[5] = acc.sxy;
+                    Store *sp = sums + 6 * slot;
+                    sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
                 }
             }
             __syncthreads();
             if (tid < nb) {
-                const uint32_t *sp = sums + 6 * tid;
                 const uint32_t pk = ids[dir * (b0 + tid)];
-                nccv[pk >> 16] = ncc_from_sums(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
+                nccv[pk >> 16] = P::ncc(sums + 6 * tid);
             }
             __syncthreads();
         }
@@ -748,6 +838,21 @@ __global__ void prep_u8_plane(const float *img, int H, int W, unsigned char *pla
     plane[(size_t)(y + pad) * Wp + (x + pad)] = ok ? (unsigned char)r : (unsigned char)0;
 }
 
+// ---- f32 image -> zero-bordered f32 plane (PxF32 policy) ---------------------------------------------
+__global__ void prep_f32_plane(const float *img, int H, int W, float *plane, int Wp, int pad)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    plane[(size_t)(y + pad) * Wp + (x + pad)] = img[(size_t)y * W + x];
+}
+
+hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp, int pad, hipStream_t s)
+{
+    dim3 blk(256), grd((W + 255) / 256, H);
+    hipLaunchKernelGGL(prep_f32_plane, grd, blk, 0, s, img, H, W, plane, Wp, pad);
+    return hipGetLastError();
+}
+
 hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, int Wp, int pad, int *d_flag, hipStream_t s)
 {
     dim3 blk(256), grd((W + 255) / 256, H);
@@ -763,7 +868,8 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     const int cells = (Dx2 - 2 * C::OCW + 1) * (Dy2 - 2 * C::OCW + 1);
     // pitch (dwords): written dwords + one zero dword, and the right-most cell's sliding read-ahead
     const int csx = Dx2 - 2 * C::OCW + 1;
-    const int pw_a = ((3 + (Dx2 - 1) + 3) >> 2) + 1, pw_b = ((3 + csx - 2) >> 2) + C::GPR + 1;
+    constexpr int G = C::P::G, LG = C::P::LOG2G;
+    const int pw_a = ((G - 1 + (Dx2 - 1) + G - 1) >> LG) + 1, pw_b = ((G - 1 + csx - 2) >> LG) + C::GPR + 1;
     a.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
     // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
@@ -781,13 +887,13 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     off = (off + 15) & ~(size_t)15; a.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
     off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
-    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += 4 * 6 * kSumBatch + 64;
+    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 64;
     off = (off + 15) & ~(size_t)15; a.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
     off = (off + 15) & ~(size_t)15;
     if (off > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_u8<C>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_px<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -806,7 +912,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     }
     a.stats = want_stats ? d_stats : nullptr;
     if (want_stats) (void)hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long) * (size_t)nb, stream);
-    hipLaunchKernelGGL(match_ncc_dlc_u8<C>, dim3(nb), dim3(C::NT), off, stream, a);
+    hipLaunchKernelGGL(match_ncc_dlc_px<C>, dim3(nb), dim3(C::NT), off, stream, a);
     if (want_stats) {
         (void)hipStreamSynchronize(stream);
         unsigned long long *hh = (unsigned long long *)malloc(8 * sizeof(unsigned long long) * (size_t)nb);
@@ -819,6 +925,23 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
                 (double)h[5] / a.N, (double)h[6] / a.N, (double)h[7] / a.N);
     }
     return hipGetLastError();
+}
+
+bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
+{
+    if (!(ocw == 7 || ocw == 15 || ocw == 16)) return false;     // chip rows must fit the register image
+    return max_reach_u + 12 <= kU8Pad && max_reach_v + 12 <= kU8Pad && max_reach_u <= 120 && max_reach_v <= 120;
+}
+
+hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+{
+    if (a.N <= 0) return hipSuccess;
+    switch (a.ocw) {
+    case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v)
@@ -834,13 +957,13 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
 {
     if (a.N <= 0) return hipSuccess;
     switch (a.ocw) {
-    case 7: return launch_cfg<U8Cfg<7, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 15: return launch_cfg<U8Cfg<15, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 16: return launch_cfg<U8Cfg<16, 16>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 7: return launch_cfg<PxCfg<PxU8, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 16: return launch_cfg<PxCfg<PxU8, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     // big chips: 4 waves share one point's LDS image (one cell per wave and round)
-    case 30: return launch_cfg<U8Cfg<30, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_cfg<U8Cfg<32, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<U8Cfg<40, 64, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU8, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<PxCfg<PxU8, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxU8, 40, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -18,12 +18,17 @@ def api():
 U8_OCW = (7, 15, 16, 30, 32, 40)   # chip sizes the exact u8 kernel is instantiated for
 
 
+F32T_OCW = (7, 15, 16)              # chip sizes of the register-tiled f32 kernel
+
+
 def expected_path(mode, i0, ocw):
     u8 = mode == "auto" and ocw in U8_OCW and float(i0.max()) <= 255.0 and np.array_equal(i0, np.rint(i0))
-    return "u8_exact" if u8 else "general_f32"
+    if u8:
+        return "u8_exact"
+    return "f32_tiled" if (mode != "general" and ocw in F32T_OCW) else "general_f32"
 
 
-@pytest.mark.parametrize("mode", ["auto", "general"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
 @pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
 def test_golden(api, path, mode):
     g = load_match_golden(path)
@@ -55,7 +60,7 @@ SMALL = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "general"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
 @pytest.mark.parametrize("kw", SMALL, ids=lambda k: f"seed{k['seed']}_ocw{k['ocw']}")
 def test_vs_oracle(api, oracle, kw, mode):
     c = synth.make_small(**kw)
@@ -72,7 +77,7 @@ def test_vs_oracle(api, oracle, kw, mode):
     assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
 
 
-@pytest.mark.parametrize("mode", ["auto", "general"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
 def test_c1_config_vs_oracle(api, oracle, mode):
     """BASELINE configs[0]: 512^2, 1,024 points, 33x33 chip / 65x65 window."""
     c = synth.make_case("C1")
@@ -106,7 +111,7 @@ def test_float_images_within_tolerance(api, oracle):
     assert np.nanmax(np.abs(got - want)) <= 1e-4
 
 
-@pytest.mark.parametrize("mode", ["auto", "general"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
 def test_long_climbs(api, oracle, mode):
     """Smooth texture + a shift far along the corridor: pivots climb 10+ scans to the peak, which
     exercises the u8 kernel's generic (sequential) replay behind the speculative one."""
