@@ -938,8 +938,8 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     if (a.N <= 0) return hipSuccess;
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }
