@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
-    ap.add_argument("--path", default="auto", choices=["auto", "general", "f32"],
+    ap.add_argument("--path", default="auto", choices=["auto", "general", "f32", "u16"],
                     help="auto: exact u8 kernel when the pair is 8-bit integral; f32: the register-tiled f32 kernel "
                          "(what 16-bit / filtered imagery gets); general: force the fallback f32 kernel")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -172,7 +172,7 @@ def main():
                        "parallelism": f"grid-point shard x{world}" + (", RCCL all-gather of [N,3]" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {"u8_exact": "match_ncc_dlc_u8", "f32_tiled": "match_ncc_dlc_px<PxF32>"}.get(ctx.last_path(), "match_ncc_dlc_f32"),
+                         "kernel": {"u8_exact": "match_ncc_dlc_u8", "f32_tiled": "match_ncc_dlc_px<PxF32>", "u16_scaled": "match_ncc_dlc_px<PxU16>"}.get(ctx.last_path(), "match_ncc_dlc_f32"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
         }

@@ -51,10 +51,13 @@ int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i
  *   1 = exact-integer u8 kernel when BOTH resident images were proven (on the device, at set_images
  *       time) to hold only integers in [0,255] -- the 8-bit TIFF case of GMA_float_load_tiff
  *       (GMA.c:288-298) -- and ocw is one of 7, 15, 16, 30, 32, 40;
+ *   3 = exact scaled-integer u16 kernel when both images hold only values q/2^s with q < 4096 (12-bit DN,
+ *       or what GMA_float_conv2 makes of 8-bit images: integers <= 511 / multiples of 1/8), same ocw set;
  *   2 = register-tiled f32 kernel (any f32 imagery) when ocw is one of 7, 15, 16;
  *   0 = general f32 kernel (any ocw, any window size) otherwise.
  * All three give results bit-identical to the reference on integral-DN data.  mode 1 forces kernel 0,
- * mode 2 skips the u8 kernel (tests use them to cover every kernel on 8-bit inputs too).
+ * mode 2 skips the integer kernels, mode 3 skips only the u8 kernel (tests use them to cover every kernel
+ * on 8-bit inputs too).
  * mimc3_ctx_last_path returns the kernel of the last call (<0 = none yet). */
 int mimc3_ctx_set_path(mimc3_ctx *ctx, int32_t mode);
 int mimc3_ctx_last_path(mimc3_ctx *ctx);

@@ -54,6 +54,10 @@ struct mimc3_ctx {
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
+    DevBuf hpl0, hpl1;                  // zero-bordered u16 planes of scaled integers (q = value * 2^shift < 4096)
+    bool u16_ok = false;                // the pair is scaled-integer (and not 8-bit): u16 planes are built
+    bool hpl_valid = false;             // u16 planes hold the CURRENT pair
+    int shift0 = 0, shift1 = 0;
     DevBuf fpl0, fpl1;                  // zero-bordered f32 planes (register-tiled f32 kernel), built on first use
     bool fplanes_ok = false;
     int32_t Wp = 0;
@@ -104,7 +108,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
-    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fpl0.release(); c->fpl1.release();
+    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fpl0.release(); c->fpl1.release(); c->hpl0.release(); c->hpl1.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -136,12 +140,38 @@ static int prepare_u8(mimc3_ctx *c)
     HIP_TRY(hipMemcpyAsync(&not_u8, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->u8_ok = (not_u8 == 0);
+    c->u16_ok = false;
+    c->hpl_valid = false;
+    if (!c->u8_ok) {
+        // not 8-bit: is the pair "scaled integer" (12-bit DN, or what GMA_float_conv2 makes of 8-bit images:
+        // integers / multiples of 1/8)?  Then the exact u16 kernel applies.
+        int fl[2] = {3, 3};
+        HIP_TRY(c->flag.reserve(2 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(c->flag.p, 0, 2 * sizeof(int), c->stream));
+        HIP_TRY(mimc3::launch_detect_scaled_int(c->d_i0, (size_t)c->H * c->W, static_cast<int *>(c->flag.p), c->stream));
+        HIP_TRY(mimc3::launch_detect_scaled_int(c->d_i1, (size_t)c->H * c->W, static_cast<int *>(c->flag.p) + 1, c->stream));
+        HIP_TRY(hipMemcpyAsync(fl, c->flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        auto pick = [](int f) { return (f & 1) == 0 ? 0 : ((f & 2) == 0 ? 3 : -1); };
+        const int s0 = pick(fl[0]), s1 = pick(fl[1]);
+        if (s0 >= 0 && s1 >= 0) {
+            const size_t hb = sizeof(unsigned short) * (size_t)(c->H + 2 * pad) * c->Wp;
+            HIP_TRY(c->hpl0.reserve(hb));
+            HIP_TRY(c->hpl1.reserve(hb));
+            HIP_TRY(hipMemsetAsync(c->hpl0.p, 0, hb, c->stream));
+            HIP_TRY(hipMemsetAsync(c->hpl1.p, 0, hb, c->stream));
+            HIP_TRY(mimc3::launch_prep_u16(c->d_i0, c->H, c->W, static_cast<unsigned short *>(c->hpl0.p), c->Wp, pad, s0, c->stream));
+            HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, pad, s1, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->shift0 = s0; c->shift1 = s1; c->u16_ok = true; c->hpl_valid = true;
+        }
+    }
     return 0;
 }
 
 extern "C" int mimc3_ctx_set_path(mimc3_ctx *c, int32_t mode)
 {
-    if (!c || mode < 0 || mode > 2) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
+    if (!c || mode < 0 || mode > 3) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
     c->path_mode = mode;
     return 0;
 }
@@ -213,8 +243,23 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     const int reach_u = max_abs_piv_u + (off_u < 0 ? -off_u : off_u), reach_v = max_abs_piv_v + (off_v < 0 ? -off_v : off_v);
     hipError_t e;
     const bool want_u8 = c->path_mode == 0 && c->u8_ok && mimc3::match_u8_supported(ocw, reach_u, reach_v);
-    const bool want_f32x = !want_u8 && c->path_mode != 1 && mimc3::match_f32x_supported(ocw, reach_u, reach_v);
-    if (want_u8 || want_f32x) {
+    bool want_u16 = !want_u8 && (c->path_mode == 0 || c->path_mode == 3) && mimc3::match_u8_supported(ocw, reach_u, reach_v);
+    if (want_u16 && !c->u16_ok) {
+        if (c->u8_ok && c->path_mode == 3 && !c->hpl_valid) {  // tests: 8-bit pairs are scaled integers too (shift 0)
+            const size_t hb = sizeof(unsigned short) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
+            HIP_TRY(c->hpl0.reserve(hb));
+            HIP_TRY(c->hpl1.reserve(hb));
+            HIP_TRY(hipMemsetAsync(c->hpl0.p, 0, hb, s));
+            HIP_TRY(hipMemsetAsync(c->hpl1.p, 0, hb, s));
+            HIP_TRY(mimc3::launch_prep_u16(c->d_i0, c->H, c->W, static_cast<unsigned short *>(c->hpl0.p), c->Wp, mimc3::kU8Pad, 0, s));
+            HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, mimc3::kU8Pad, 0, s));
+            c->shift0 = c->shift1 = 0;
+            c->hpl_valid = true;
+        }
+        want_u16 = c->u8_ok && c->path_mode == 3;
+    }
+    const bool want_f32x = !want_u8 && !want_u16 && c->path_mode != 1 && mimc3::match_f32x_supported(ocw, reach_u, reach_v);
+    if (want_u8 || want_u16 || want_f32x) {
         mimc3::MatchU8Args u{};
         u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W; u.thr = a.thr;
         u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
@@ -229,6 +274,11 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
             e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 1;
+        } else if (want_u16) {
+            u.p0 = static_cast<const unsigned char *>(c->hpl0.p); u.p1 = static_cast<const unsigned char *>(c->hpl1.p);
+            u.scale0 = 1.0 / (double)(1 << c->shift0); u.scale1 = 1.0 / (double)(1 << c->shift1);
+            e = mimc3::launch_match_u16(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+            c->last_path = 3;
         } else {
             if (!c->fplanes_ok) {      // zero-bordered f32 copies of the pair, once per image pair
                 const size_t bytes = sizeof(float) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;

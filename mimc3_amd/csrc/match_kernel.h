@@ -32,6 +32,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     const unsigned char *p0, *p1;   // zero-bordered planes of i0, i1 (u8 or f32 pixels): pixel (u,v) at [(v+pad)*Wp + u+pad]
     int32_t Wp, pad;                // plane pitch (PIXELS; a whole number of dwords) and border
     float thr;                      // smallest f32 whose f64 value is >= MIN_DN (f32 policy)
+    double scale0, scale1;          // u16 policy: plane k stores value * 2^s_k; scale_k = 2^-s_k (1.0 otherwise)
     int32_t H, W;
     const double *xyuvav;
     int32_t N;
@@ -54,6 +55,10 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
 hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, int Wp, int pad, int *d_flag, hipStream_t s);
 // instantiated chip sizes and border reach (|last pivot| + |CP offset| must fit in the border)
 bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v);
+// same kernel family on zero-bordered u16 planes of scaled integers (q = value * 2^shift < 4096): same chip sizes as u8
+hipError_t launch_detect_scaled_int(const float *img, size_t n, int *d_flags, hipStream_t s);
+hipError_t launch_prep_u16(const float *img, int H, int W, unsigned short *plane, int Wp, int pad, int shift, hipStream_t s);
+hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 // same kernel family on zero-bordered f32 planes (any f32 imagery; small chips only)
 hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp, int pad, hipStream_t s);
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v);

@@ -136,11 +136,88 @@ struct PxU8 {
     typedef uint32_t Store;                                    // how a reduced sum is parked in LDS
     __device__ static __forceinline__ Store bits(Sum v) { return v; }
     // NCC from exact integer sums (MIMC_module.c:734), f64, no contraction
-    __device__ static __forceinline__ float ncc(const Store *sp)
+    __device__ static __forceinline__ float ncc(const Store *sp, double, double)
     {
         const double dn = (double)sp[0], dsx = (double)sp[1], dsy = (double)sp[2];
         const double num = dn * (double)sp[5] - dsx * dsy;
         const double den = sqrt((dn * (double)sp[3] - dsx * dsx) * (dn * (double)sp[4] - dsy * dsy));
+        return (float)(num / den);
+    }
+};
+
+// ---- pixel policy: scaled-integer imagery q = value * 2^s with q < 4096 (12 bits), 2 pixels per dword.
+//      Covers 12-bit DN and what GMA_float_conv2 makes of 8-bit images (gradients: integers <= 511;
+//      Laplacian: multiples of 1/8, MIMC_main.c:175-196).  The reference's f32 products q_a*q_b/2^(s_a+s_b)
+//      are exact (< 2^24 significant bits), so exact integer sums rescaled by powers of two in f64 are the
+//      reference's sums.  Per-lane partial sums fit 32 bits; the cross-lane reduction is 64-bit. -----------
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+__device__ __forceinline__ uint32_t nz8000(uint32_t v) { return (((v & 0x7fff7fffu) + 0x7fff7fffu) | v) & 0x80008000u; }
+__device__ __forceinline__ uint32_t ffff_from8000(uint32_t t) { return t | (t - (t >> 15)); }
+__device__ __forceinline__ unsigned long long dpp_add_u64(unsigned long long x, int ctrl_sel)
+{
+    int lo = (int)(uint32_t)x, hi = (int)(uint32_t)(x >> 32);
+    int olo, ohi;
+    switch (ctrl_sel) {
+    case 0: olo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: olo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: olo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: olo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); ohi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
+    }
+    return x + (((unsigned long long)(uint32_t)ohi << 32) | (uint32_t)olo);
+}
+struct PxU16 {
+    static constexpr int BPP = 2, G = 2, LOG2G = 1;
+    typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
+    static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
+    __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
+    __device__ static __forceinline__ int npx(uint32_t m) { return __popc(m & 0x00010001u); }
+    __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float) { return npx(keep) - __popc(nz8000(v) >> 15); }   // null <=> q == 0
+    __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return nbad(v, keep, thr); }
+    __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float) { return a; }
+    __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a)
+    {
+        sx = dot2(a, 0x00010001u, (uint32_t)sx); sxx = dot2(a, a, (uint32_t)sxx);
+    }
+    template <int MODE>
+    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t, uint32_t padff, bool static_pad, uint32_t bw, float)
+    {
+        const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ffff_from8000(nz8000(a));
+        if (MODE == M_FAST || MODE == M_CHIPNULL) {
+            acc.sy = dot2(mf & 0x00010001u, bw, (uint32_t)acc.sy);
+            acc.syy = dot2((MODE == M_FAST && static_pad && padff == 0xffffffffu) ? bw : (bw & mf), bw, (uint32_t)acc.syy);
+            acc.sxy = dot2(a, bw, (uint32_t)acc.sxy);
+        } else {
+            const uint32_t t = nz8000(bw);
+            const uint32_t mb01 = t >> 15, mbff = ffff_from8000(t);
+            const uint32_t ma01 = mf & 0x00010001u;
+            acc.n = dot2(ma01, mb01, acc.n);
+            acc.sx = dot2(a, mb01, (uint32_t)acc.sx);
+            acc.sy = dot2(ma01, bw, (uint32_t)acc.sy);
+            acc.sxy = dot2(a, bw, (uint32_t)acc.sxy);
+            acc.sxx = dot2(a & mbff, a, (uint32_t)acc.sxx);
+            acc.syy = dot2(bw & mf, bw, (uint32_t)acc.syy);
+        }
+    }
+    template <int LPC> __device__ static __forceinline__ Sum gsum(Sum v)
+    {
+        v = dpp_add_u64(v, 0); v = dpp_add_u64(v, 1); v = dpp_add_u64(v, 2); v = dpp_add_u64(v, 3);
+        if (LPC >= 32) v += __shfl_xor(v, 16, 64);
+        if (LPC >= 64) v += __shfl_xor(v, 32, 64);
+        return v;
+    }
+    typedef unsigned long long Store;
+    __device__ static __forceinline__ Store bits(Sum v) { return v; }
+    __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb)
+    {
+        const double dn = (double)(uint32_t)sp[0];
+        const double sx = (double)sp[1] * sa, sy = (double)sp[2] * sb;            // exact: powers of two
+        const double sxx = (double)sp[3] * (sa * sa), syy = (double)sp[4] * (sb * sb), sxy = (double)sp[5] * (sa * sb);
+        const double num = dn * sxy - sx * sy;
+        const double den = sqrt((dn * sxx - sx * sx) * (dn * syy - sy * sy));
         return (float)(num / den);
     }
 };
@@ -189,7 +266,7 @@ struct PxF32 {
     }
     typedef unsigned long long Store;
     __device__ static __forceinline__ Store bits(Sum v) { return (unsigned long long)__double_as_longlong(v); }
-    __device__ static __forceinline__ float ncc(const Store *sp)
+    __device__ static __forceinline__ float ncc(const Store *sp, double, double)
     {
         const double dn = (double)(uint32_t)sp[0];
         const double sx = __longlong_as_double((long long)sp[1]), sy = __longlong_as_double((long long)sp[2]);
@@ -317,6 +394,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     const int wv0 = v0 + p.off_v - pt.dy2 + PAD;     // plane row of window row 0
     pt.sh = wu0 & (P::G - 1);                        // pixel phase of window column 0 inside its aligned dword
     pt.thr = p.thr;
+    // scaled-integer planes store q = value * 2^s: the sums are rescaled exactly (powers of two) in the finish
+    const double sc_chip = p.swap ? p.scale1 : p.scale0, sc_win = p.swap ? p.scale0 : p.scale1;
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
@@ -579,7 +658,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             __syncthreads();
             if (tid < nb) {
                 const uint32_t pk = ids[dir * (b0 + tid)];
-                nccv[pk >> 16] = P::ncc(sums + 6 * tid);
+                nccv[pk >> 16] = P::ncc(sums + 6 * tid, sc_chip, sc_win);
             }
             __syncthreads();
         }
@@ -838,6 +917,36 @@ __global__ void prep_u8_plane(const float *img, int H, int W, unsigned char *pla
     plane[(size_t)(y + pad) * Wp + (x + pad)] = ok ? (unsigned char)r : (unsigned char)0;
 }
 
+// ---- f32 image -> zero-bordered u16 plane of q = value * 2^s (PxU16 policy) --------------------------
+// flags bit0: some pixel is not an integer in [0,4095]; bit1: some pixel*8 is not an integer in [0,4095]
+__global__ void detect_scaled_int(const float *img, size_t n, int *flags)
+{
+    int f = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = img[i], v8 = v * 8.0f;
+        if (!(v >= 0.0f && v <= 4095.0f && truncf(v) == v)) f |= 1;
+        if (!(v8 >= 0.0f && v8 <= 4095.0f && truncf(v8) == v8)) f |= 2;
+    }
+    if (f) atomicOr(flags, f);
+}
+__global__ void prep_u16_plane(const float *img, int H, int W, unsigned short *plane, int Wp, int pad, float mul)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    plane[(size_t)(y + pad) * Wp + (x + pad)] = (unsigned short)(img[(size_t)y * W + x] * mul);
+}
+hipError_t launch_detect_scaled_int(const float *img, size_t n, int *d_flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(detect_scaled_int, dim3(2048), dim3(256), 0, s, img, n, d_flags);
+    return hipGetLastError();
+}
+hipError_t launch_prep_u16(const float *img, int H, int W, unsigned short *plane, int Wp, int pad, int shift, hipStream_t s)
+{
+    dim3 blk(256), grd((W + 255) / 256, H);
+    hipLaunchKernelGGL(prep_u16_plane, grd, blk, 0, s, img, H, W, plane, Wp, pad, (float)(1 << shift));
+    return hipGetLastError();
+}
+
 // ---- f32 image -> zero-bordered f32 plane (PxF32 policy) ---------------------------------------------
 __global__ void prep_f32_plane(const float *img, int H, int W, float *plane, int Wp, int pad)
 {
@@ -940,6 +1049,20 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+{
+    if (a.N <= 0) return hipSuccess;
+    switch (a.ocw) {
+    case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 16: return launch_cfg<PxCfg<PxU16, 16, 32, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -21,14 +21,19 @@ U8_OCW = (7, 15, 16, 30, 32, 40)   # chip sizes the exact u8 kernel is instantia
 F32T_OCW = (7, 15, 16)              # chip sizes of the register-tiled f32 kernel
 
 
-def expected_path(mode, i0, ocw):
-    u8 = mode == "auto" and ocw in U8_OCW and float(i0.max()) <= 255.0 and np.array_equal(i0, np.rint(i0))
-    if u8:
+def expected_path(mode, i0, ocw, i1=None):
+    imgs = [i0] if i1 is None else [i0, i1]
+    is_u8 = all(float(i.max()) <= 255.0 and float(i.min()) >= 0 and np.array_equal(i, np.rint(i)) for i in imgs)
+    is_si = all(float(i.min()) >= 0 and ((float(i.max()) <= 4095.0 and np.array_equal(i, np.rint(i))) or
+                (float(i.max()) * 8 <= 4095.0 and np.array_equal(i * 8, np.rint(i * 8)))) for i in imgs)
+    if mode == "auto" and ocw in U8_OCW and is_u8:
         return "u8_exact"
+    if ocw in U8_OCW and ((mode == "auto" and is_si and not is_u8) or (mode == "u16" and is_u8)):
+        return "u16_scaled"
     return "f32_tiled" if (mode != "general" and ocw in F32T_OCW) else "general_f32"
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
 @pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
 def test_golden(api, path, mode):
     g = load_match_golden(path)
@@ -38,7 +43,7 @@ def test_golden(api, path, mode):
         ctx.set_images(g["i0"], g["i1"])
         ctx.set_path(mode)
         out = ctx.matching_ncc_dlc_2(g["xyuvav"], g["offset"], off, uv, g["ocw"])
-        assert ctx.last_path() == expected_path(mode, g["i0"], g["ocw"])
+        assert ctx.last_path() == expected_path(mode, g["i0"], g["ocw"], g["i1"])
         assert_bits_equal(out, g["out"], "forward")
         out_sw = ctx.matching_ncc_dlc_2(g["xyuvav"], -g["offset"], off, -uv, g["ocw"], swap=True)
         assert_bits_equal(out_sw, g["out_swapped"], "swapped")
@@ -60,7 +65,7 @@ SMALL = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
 @pytest.mark.parametrize("kw", SMALL, ids=lambda k: f"seed{k['seed']}_ocw{k['ocw']}")
 def test_vs_oracle(api, oracle, kw, mode):
     c = synth.make_small(**kw)
@@ -71,13 +76,13 @@ def test_vs_oracle(api, oracle, kw, mode):
         ctx.set_images(c.i0, c.i1)
         ctx.set_path(mode)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == expected_path(mode, c.i0, c.ocw)
+        assert ctx.last_path() == expected_path(mode, c.i0, c.ocw, c.i1)
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
     assert_bits_equal(got, want)
     assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
 def test_c1_config_vs_oracle(api, oracle, mode):
     """BASELINE configs[0]: 512^2, 1,024 points, 33x33 chip / 65x65 window."""
     c = synth.make_case("C1")
@@ -111,7 +116,7 @@ def test_float_images_within_tolerance(api, oracle):
     assert np.nanmax(np.abs(got - want)) <= 1e-4
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32"])
+@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
 def test_long_climbs(api, oracle, mode):
     """Smooth texture + a shift far along the corridor: pivots climb 10+ scans to the peak, which
     exercises the u8 kernel's generic (sequential) replay behind the speculative one."""
@@ -161,6 +166,31 @@ def test_u8_cache_overflow_hands_points_to_general_kernel(oracle):
     want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
     assert_bits_equal(outs[0], want, "all points overflowed")
     assert_bits_equal(outs[1], want, "normal cache")
+
+
+@pytest.mark.parametrize("kind", ["12bit", "eighths", "mixed"])
+@pytest.mark.parametrize("ocw", [7, 16, 30])
+def test_scaled_integer_planes(api, oracle, kind, ocw):
+    """12-bit DN and multiples of 1/8 (what the CLI's Laplacian filter produces, MIMC_main.c:188-196) go
+    through the exact u16 kernel: every f32 product of the reference is exact, sums rescale by powers of two."""
+    c = synth.make_small(seed=110 + ocw, shift=(3, -2), angle_deg=33.0, ocw=ocw, speed=1400.0, h=300, w=310, dimx=6, dimy=5,
+                         bits=12, null_frac=0.05, noise_dn=3)
+    i0, i1 = c.i0, c.i1
+    if kind == "eighths":
+        i0, i1 = (i0 / 8).astype(np.float32), (i1 / 8).astype(np.float32)
+    elif kind == "mixed":
+        i1 = (i1 / 8).astype(np.float32)
+    H, W = i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+    want = oracle.match(i0, i1, c.xyuvav, c.offset, off, uv, ocw)
+    want_sw = oracle.match(i1, i0, c.xyuvav, -c.offset, off, -uv, ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(i0, i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+        assert ctx.last_path() == "u16_scaled"
+        sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
+    assert_bits_equal(got, want)
+    assert_bits_equal(sw, want_sw, "swapped")
 
 
 def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
