@@ -33,6 +33,10 @@ MATCH_CASES = {
     "offcorridor_q2": dict(seed=104, shift=(-4, -1), angle_deg=135.0, ocw=7, speed=1400.0),
     # 16-bit DN (f32 products round, T1), non-zero CP offset applied to the window only (T6)
     "u16_offset": dict(seed=105, shift=(5, -3), angle_deg=20.0, ocw=9, speed=1600.0, bits=16, offset=(2, -1)),
+    # T3, observable laziness: horizontal corridor (window only ocw+2 rows tall each side), true shift 2 px
+    # off it: the climb leaves through the boundary break (:703-707) and the fit reads -2.0 cells
+    "t3_break_horizontal": dict(seed=107, shift=(3, 2), angle_deg=0.0, ocw=7, speed=1200.0),
+    "t3_break_vertical": dict(seed=109, shift=(-2, 3), angle_deg=90.0, ocw=7, speed=1300.0),
     # grid so close to the border that windows hang over the image edge (zero fill, :877-884)
     "edge_windows": dict(seed=106, shift=(1, -1), angle_deg=60.0, ocw=7, speed=900.0, margin=10,
                          h=120, w=128, dimx=10, dimy=9),
