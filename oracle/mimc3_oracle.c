@@ -419,3 +419,208 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* =========================================================================================
+ * N1  candidate clustering, dpf0, dpf1                         MIMC_module.c:994-1263, :1330-1718
+ * (the stages between the 32 matcher passes and the QM update)
+ * ======================================================================================= */
+/* dp: [ndp][N][3] matcher outputs.  mvn: padded [N][Kmax][5], nclus[N].  Returns the largest cluster
+ * count, or -1 if it exceeds Kmax.  (calc_mean_var_num_dp_cluster :994-1130, cluster_euclidian :1133-1180;
+ * single linkage < 0.5 px: clusters are the connected components, numbered by their first member) */
+int32_t orc_cluster_candidates(const float *dp, int32_t ndp, int32_t N, int32_t Kmax, float *mvn, int32_t *nclus)
+{
+    const float min_ncc = 0.1, min_dist = 0.5;
+    const float min_dist_sq = min_dist * min_dist;
+    int32_t kmax_seen = 0;
+    float *px = (float *)malloc(sizeof(float) * ndp), *py = (float *)malloc(sizeof(float) * ndp);
+    int *lab = (int *)malloc(sizeof(int) * ndp), *todo = (int *)malloc(sizeof(int) * ndp);
+    float *sx = (float *)malloc(sizeof(float) * ndp), *sy = (float *)malloc(sizeof(float) * ndp);
+    float *sxx = (float *)malloc(sizeof(float) * ndp), *syy = (float *)malloc(sizeof(float) * ndp);
+    int *cnt = (int *)malloc(sizeof(int) * ndp);
+    memset(mvn, 0, sizeof(float) * 5 * (size_t)N * Kmax);
+    for (int32_t g = 0; g < N; g++) {
+        int nv = 0;
+        for (int k = 0; k < ndp; k++) {
+            const float *o = dp + ((size_t)k * N + g) * 3;
+            if (o[2] > min_ncc) { px[nv] = o[0]; py[nv] = o[1]; nv++; }
+        }
+        int ncl = 0;
+        for (int i = 0; i < nv; i++) lab[i] = 0;
+        for (int i = 0; i < nv; i++) {
+            if (lab[i]) continue;
+            ncl++;
+            /* grow the component of i.  NOTE the reference seeds with mark_row(i): i itself is labelled only
+             * through its own diagonal entry d(i,i)=0 < 0.25 -- false when the candidate is NaN, in which case it
+             * keeps label 0 and is revisited... the recursion then never labels it: reproduce via the same test */
+            int nt = 0; todo[nt++] = i;
+            int self = 0;
+            { float dx = px[i] - px[i], dy = py[i] - py[i]; self = (dx * dx + dy * dy < min_dist_sq); }
+            if (self) lab[i] = ncl;
+            while (nt) {
+                int r = todo[--nt];
+                for (int c = 0; c < nv; c++) {
+                    float dx = px[c] - px[r], dy = py[c] - py[r];
+                    if (dx * dx + dy * dy < min_dist_sq && lab[c] == 0) { lab[c] = ncl; todo[nt++] = c; }
+                }
+            }
+        }
+        /* max id actually used (a NaN candidate consumes an id without ever carrying it) */
+        int max_id = 0;
+        for (int i = 0; i < nv; i++) if (lab[i] > max_id) max_id = lab[i];
+        if (max_id > kmax_seen) kmax_seen = max_id;
+        nclus[g] = max_id;
+        if (max_id > Kmax) continue;
+        for (int c = 0; c < max_id; c++) { sx[c] = sy[c] = sxx[c] = syy[c] = 0; cnt[c] = 0; }
+        for (int i = 0; i < nv; i++) {
+            if (lab[i] == 0) continue;          /* reference indexes sx[-1] here (UB); never happens for finite candidates */
+            int c = lab[i] - 1;
+            sx[c] += px[i]; sy[c] += py[i];
+            sxx[c] += px[i] * px[i]; syy[c] += py[i] * py[i];
+            cnt[c] += 1;
+        }
+        float *m = mvn + (size_t)g * Kmax * 5;
+        for (int c = 0; c < max_id; c++) {
+            m[5 * c + 0] = sx[c] / (float)cnt[c];
+            m[5 * c + 1] = sy[c] / (float)cnt[c];
+            m[5 * c + 2] = sxx[c] / (float)cnt[c] - m[5 * c + 0] * m[5 * c + 0];
+            m[5 * c + 3] = syy[c] / (float)cnt[c] - m[5 * c + 1] * m[5 * c + 1];
+            m[5 * c + 4] = (float)cnt[c] / (float)ndp;
+        }
+    }
+    free(px); free(py); free(lab); free(todo); free(sx); free(sy); free(sxx); free(syy); free(cnt);
+    return kmax_seen > Kmax ? -1 : kmax_seen;
+}
+
+/* get_dpf0 (:1224-1263): first cluster whose fraction exceeds the ratio, else -1 */
+void orc_get_dpf0(const float *mvn, const int32_t *nclus, int32_t N, int32_t Kmax, float min_ratio, int32_t *dpf)
+{
+    for (int32_t g = 0; g < N; g++) {
+        dpf[g] = -1;
+        for (int32_t c = 0; c < nclus[g]; c++)
+            if (mvn[((size_t)g * Kmax + c) * 5 + 4] > min_ratio) { dpf[g] = c; break; }
+    }
+}
+
+/* get_dpf1 (:1330-1718): a-priori-scaled neighbour interpolation of the unassigned points (Jacobi sweeps),
+ * 3x3 smoothing, snap to the nearest cluster.  dpf in/out, dx/dy out.  Returns the sweep count (NOI). */
+int32_t orc_get_dpf1(int32_t dimy, int32_t dimx, int32_t *dpf, float *dx, float *dy, const int32_t *ruv, int32_t nn,
+                     const float *mvn, int32_t Kmax, const int32_t *nclus, const double *xyuvav, float dt, float mpp)
+{
+    const int32_t N = dimx * dimy;
+    const float nanv = sqrt(-1.0);
+    float *bx = (float *)malloc(sizeof(float) * N), *by = (float *)malloc(sizeof(float) * N);
+    float *noi = (float *)malloc(sizeof(float) * N);
+    float (*v)[7] = (float (*)[7])malloc(sizeof(float) * 7 * (size_t)nn);
+    for (int32_t i = 0; i < N; i++) {
+        noi[i] = 1.0;
+        if (dpf[i] >= 0) { dx[i] = mvn[((size_t)i * Kmax + dpf[i]) * 5]; dy[i] = mvn[((size_t)i * Kmax + dpf[i]) * 5 + 1]; }
+        else { dx[i] = nanv; dy[i] = nanv; }
+        bx[i] = nanv; by[i] = nanv;
+    }
+    int32_t NOI = 0, unprocessed = 1;
+    for (int32_t thres_num = nn - 1; thres_num >= 3; thres_num--) {
+        float thres_weight = 0.5;
+        const float factor = 1.0 / 365.0 * dt / mpp;
+        while (unprocessed != 0 && thres_weight >= 0.5) {
+            thres_weight -= 0.02;
+            int32_t processed = 1;
+            while (processed != 0) {
+                NOI++;
+                processed = 0;
+                for (int32_t cv = 0; cv < dimy; cv++)
+                    for (int32_t cu = 0; cu < dimx; cu++) {
+                        const int32_t g = cv * dimx + cu;
+                        if (!(isnan(dx[g] + dy[g]) && nclus[g] != 0)) continue;
+                        int32_t num = 0;
+                        float dpe[2];
+                        dpe[0] = xyuvav[6 * (size_t)g + 4] * factor;
+                        dpe[1] = -xyuvav[6 * (size_t)g + 5] * factor;
+                        const float mag_dpe = sqrt(dpe[0] * dpe[0] + dpe[1] * dpe[1]);
+                        for (int32_t k = 0; k < nn; k++) {
+                            const int32_t u = cu + ruv[2 * k], w = cv + ruv[2 * k + 1];
+                            if (u < 0 || u >= dimx || w < 0 || w >= dimy) continue;
+                            const int32_t h = w * dimx + u;
+                            const float n0 = dx[h], n1 = dy[h];
+                            if (isnan(n0 + n1)) continue;
+                            const float a0 = (float)(xyuvav[6 * (size_t)h + 4]) * factor;
+                            const float a1 = -(float)(xyuvav[6 * (size_t)h + 5]) * factor;
+                            v[num][0] = (float)ruv[2 * k]; v[num][1] = (float)ruv[2 * k + 1];
+                            v[num][4] = sqrt(n0 * n0 + n1 * n1);
+                            v[num][5] = sqrt(a0 * a0 + a1 * a1);
+                            v[num][6] = noi[h];
+                            v[num][3] = v[num][4] / sqrt(a0 * a0 + a1 * a1);
+                            num++;
+                        }
+                        if (num < thres_num) continue;
+                        float w_min = 1E+37, w_max = -1E+37;
+                        const float max_noi = 1.0;
+                        int32_t id_max = 0, id_min = 0;
+                        for (int32_t i = 0; i < num; i++) {
+                            const float d0 = v[i][0], d1 = v[i][1];
+                            const float mag = sqrt(d0 * d0 + d1 * d1);
+                            float wc = (dpe[0] * d0 + dpe[1] * d1) / (mag_dpe * mag);
+                            wc = wc > 0 ? wc : -wc;
+                            if (wc >= thres_weight) {
+                                v[i][2] = wc;
+                                if (v[i][3] > w_max) { w_max = v[i][3]; id_max = i; }
+                                if (v[i][3] < w_min) { w_min = v[i][3]; id_min = i; }
+                            } else v[i][2] = 0.0;
+                        }
+                        v[id_max][2] = 0.0; v[id_min][2] = 0.0;
+                        float s_mw = 0.0, s_w = 0.0, s_w2 = 0.0, w2, s_wdp = 0.0, s_wdpe = 0.0, s_noi = 0.0;
+                        for (int32_t i = 0; i < num; i++) {
+                            w2 = 1 / (1 + expf(-v[i][5] + 5)) / max_noi;
+                            s_mw += v[i][2] * v[i][3] * w2;
+                            s_w += v[i][2];
+                            s_wdp += v[i][2] * w2 * v[i][4] / v[i][6];
+                            s_wdpe += v[i][2] * w2 * v[i][5] / v[i][6];
+                            s_noi += v[i][6];
+                            s_w2 += v[i][2] * w2 / v[i][6];
+                        }
+                        (void)s_mw; (void)s_w2;
+                        if (s_w >= 1.0) {
+                            const float fm = s_wdp / s_wdpe;
+                            bx[g] = dpe[0] * fm; by[g] = dpe[1] * fm;
+                            noi[g] = s_noi / num + 1;
+                            processed++;
+                        }
+                    }
+                for (int32_t i = 0; i < N; i++)
+                    if (!isnan(bx[i]) && !isnan(by[i])) { dx[i] = bx[i]; dy[i] = by[i]; bx[i] = nanv; by[i] = nanv; }
+            }
+            unprocessed = 0;
+            for (int32_t i = 0; i < N; i++)
+                if ((isnan(dx[i]) || isnan(dy[i])) && nclus[i] != 0) unprocessed++;
+        }
+    }
+    /* 3x3 smoothing of the interpolated interior points (:1623-1666) */
+    for (int32_t cv = 1; cv < dimy - 1; cv++)
+        for (int32_t cu = 1; cu < dimx - 1; cu++) {
+            const int32_t g = cv * dimx + cu;
+            if (dpf[g] < 0 && !isnan(dx[g] + dy[g])) {
+                float nd = 0.0, sxs = 0.0, sys = 0.0;
+                for (int32_t b = -1; b <= 1; b++)
+                    for (int32_t a = -1; a <= 1; a++) {
+                        const int32_t h = (cv + b) * dimx + cu + a;
+                        if (!isnan(dx[h] + dy[h])) { sxs += dx[h]; sys += dy[h]; nd = nd + 1; }
+                    }
+                bx[g] = sxs / nd; by[g] = sys / nd;
+            } else { bx[g] = dx[g]; by[g] = dy[g]; }
+        }
+    for (int32_t cv = 1; cv < dimy - 1; cv++)
+        for (int32_t cu = 1; cu < dimx - 1; cu++) { const int32_t g = cv * dimx + cu; dx[g] = bx[g]; dy[g] = by[g]; }
+    /* snap to the nearest cluster (:1680-1706) */
+    for (int32_t g = 0; g < N; g++) {
+        if (!(dpf[g] < 0 && nclus[g] != 0)) continue;
+        float best = 1E+37; int32_t id = 0;
+        const float *m = mvn + (size_t)g * Kmax * 5;
+        for (int32_t c = 0; c < nclus[g]; c++) {
+            const float d0 = dx[g] - m[5 * c], d1 = dy[g] - m[5 * c + 1];
+            const float sq = d0 * d0 + d1 * d1;
+            if (sq < best) { best = sq; id = c; }
+        }
+        dpf[g] = id; dx[g] = m[5 * id]; dy[g] = m[5 * id + 1];
+    }
+    free(bx); free(by); free(noi); free(v);
+    return NOI;
+}

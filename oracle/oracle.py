@@ -63,6 +63,20 @@ class Oracle:
             self._prep.restype = C.c_int32
             self._prep.argtypes = [_f32p, C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, _f32p, _i32p, _i32p, _f32p, _f32p]
+        # N1: clustering, dpf0, dpf1
+        self._clu = getattr(self.lib, p + "cluster_candidates")
+        self._clu.restype = C.c_int32
+        self._clu.argtypes = [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _i32p]
+        self._d0 = getattr(self.lib, p + "get_dpf0")
+        self._d0.restype = None
+        if kind == "port":
+            self._d0.argtypes = [_f32p, _i32p, C.c_int32, C.c_int32, C.c_float, _i32p]
+        else:
+            self._d0.argtypes = [_f32p, _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, _i32p]
+        self._d1 = getattr(self.lib, p + "get_dpf1")
+        self._d1.restype = C.c_int32
+        self._d1.argtypes = [C.c_int32, C.c_int32, _i32p, _f32p, _f32p, _i32p, C.c_int32, _f32p, C.c_int32, _i32p, _f64p,
+                             C.c_float, C.c_float]
         self._nthr = getattr(self.lib, p + "num_threads")
         self._nthr.restype = C.c_int
 
@@ -123,6 +137,40 @@ class Oracle:
             return d, x, y, stats
         self._qm(dimy, dimx, d, x, y, ruv, ruv.shape[0], mvn, kmax, nclus, xy)
         return d, x, y, None
+
+    # -- N1 ---------------------------------------------------------------------------------
+    def cluster_candidates(self, dp, kmax=32):
+        """calc_mean_var_num_dp_cluster (:994-1130): dp [ndp][N][3] -> (mvn [N][kmax][5], nclus [N])."""
+        dp = np.ascontiguousarray(dp, np.float32)
+        ndp, n, _ = dp.shape
+        mvn = np.zeros((n, kmax, 5), np.float32)
+        nclus = np.zeros(n, np.int32)
+        rc = self._clu(dp, ndp, n, kmax, mvn, nclus)
+        if rc < 0:
+            raise ValueError("more clusters than kmax")
+        return mvn, nclus
+
+    def get_dpf0(self, mvn, nclus, dimx, dimy, min_ratio=0.6):
+        mvn = np.ascontiguousarray(mvn, np.float32)
+        nclus = np.ascontiguousarray(nclus, np.int32)
+        dpf = np.zeros(dimx * dimy, np.int32)
+        if self.kind == "port":
+            self._d0(mvn, nclus, dimx * dimy, mvn.shape[1], min_ratio, dpf)
+        else:
+            self._d0(mvn, nclus, dimx, dimy, mvn.shape[1], min_ratio, dpf)
+        return dpf.reshape(dimy, dimx)
+
+    def get_dpf1(self, dpf0, ruv, mvn, nclus, xyuvav, dt, mpp):
+        """get_dpf1 (:1330-1718) -> (dpf, dx, dy); inputs untouched."""
+        dimy, dimx = dpf0.shape
+        d = np.array(dpf0, np.int32, order="C")
+        x = np.zeros((dimy, dimx), np.float32)
+        y = np.zeros((dimy, dimx), np.float32)
+        ruv = np.ascontiguousarray(ruv, np.int32)
+        mvn = np.ascontiguousarray(mvn, np.float32)
+        self._d1(dimy, dimx, d.reshape(-1), x.reshape(-1), y.reshape(-1), ruv, ruv.shape[0], mvn, mvn.shape[1],
+                 np.ascontiguousarray(nclus, np.int32), np.ascontiguousarray(xyuvav, np.float64), dt, mpp)
+        return d, x, y
 
     # -- reference only: candidates -> QM input (N1 rows, used to make realistic fixtures) ----
     def postprocess_prep(self, dp, xyuvav, dimx, dimy, dt, mpp, meter_per_spacing, radius_dpf1=3.0, kmax=32):

@@ -235,3 +235,59 @@ int ref_get_dpf_pseudosmoothing(int32_t dimy, int32_t dimx, int32_t *dpf, float 
 }
 
 int ref_num_threads(void) { return omp_get_max_threads(); }
+
+/* ------------------------------------------------------------------------------------------
+ * N1 stages one by one (the pieces ref_postprocess_prep chains): used to pin the restatement of
+ * calc_mean_var_num_dp_cluster (:994-1130), get_dpf0 (:1224-1263) and get_dpf1 (:1330-1718).
+ * ---------------------------------------------------------------------------------------- */
+int32_t ref_cluster_candidates(const float *dp, int32_t ndp, int32_t N, int32_t Kmax, float *mvn, int32_t *nclus)
+{
+    GMA_float **dps = (GMA_float **)calloc((size_t)ndp, sizeof(GMA_float *));
+    for (int32_t k = 0; k < ndp; k++) dps[k] = wrap_float(dp + (size_t)k * N * 3, N, 3);
+    GMA_float **m = calc_mean_var_num_dp_cluster(dps, ndp);
+    int32_t kmax = 0;
+    for (int32_t g = 0; g < N; g++) if (m[g]->nrows > kmax) kmax = m[g]->nrows;
+    if (kmax <= Kmax) {
+        memset(mvn, 0, sizeof(float) * 5 * (size_t)N * Kmax);
+        for (int32_t g = 0; g < N; g++) {
+            nclus[g] = m[g]->nrows;
+            memcpy(mvn + (size_t)g * Kmax * 5, m[g]->data, sizeof(float) * 5 * (size_t)m[g]->nrows);
+        }
+    }
+    for (int32_t g = 0; g < N; g++) GMA_float_destroy(m[g]);
+    free(m);
+    for (int32_t k = 0; k < ndp; k++) UNWRAP(dps[k]);
+    free(dps);
+    return kmax <= Kmax ? kmax : -1;
+}
+
+void ref_get_dpf0(const float *mvn, const int32_t *nclus, int32_t dimx, int32_t dimy, int32_t Kmax, float min_ratio, int32_t *dpf)
+{
+    const int32_t N = dimx * dimy;
+    dimx_vmap = dimx; dimy_vmap = dimy; num_grid = N;
+    GMA_float **m = mvn_from_padded(mvn, nclus, N, Kmax);
+    GMA_int32 *d = get_dpf0(m, min_ratio);
+    memcpy(dpf, d->data, sizeof(int32_t) * (size_t)N);
+    GMA_int32_destroy(d);
+    for (int32_t g = 0; g < N; g++) GMA_float_destroy(m[g]);
+    free(m);
+}
+
+int ref_get_dpf1(int32_t dimy, int32_t dimx, int32_t *dpf, float *dx, float *dy, const int32_t *ruv, int32_t nn,
+                 const float *mvn, int32_t Kmax, const int32_t *nclus, const double *xyuvav, float dt_, float mpp)
+{
+    const int32_t N = dimx * dimy;
+    dimx_vmap = dimx; dimy_vmap = dimy; num_grid = N; dt = dt_; param_mimc2.mpp = mpp;
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_int32 *gd = wrap_int32(dpf, dimy, dimx);
+    GMA_float *gx = wrap_float(dx, dimy, dimx), *gy = wrap_float(dy, dimy, dimx);
+    GMA_int32 *gr = wrap_int32(ruv, nn, 2);
+    GMA_float **m = mvn_from_padded(mvn, nclus, N, Kmax);
+    int sv; quiet_begin(&sv);
+    get_dpf1(gd, gx, gy, gr, m, xy);
+    quiet_end(sv);
+    for (int32_t g = 0; g < N; g++) GMA_float_destroy(m[g]);
+    free(m);
+    UNWRAP(gr); UNWRAP(gx); UNWRAP(gy); UNWRAP(gd); UNWRAP(xy);
+    return 0;
+}

@@ -89,6 +89,26 @@ def main():
             dpf_out=d2, dx_out=x2, dy_out=y2)
         print(f"{name}: nn={ruv.shape[0]} kmax={kmax} changed={(d2 != dpf).sum()}")
 
+    # N1: candidates -> clustering -> dpf0 -> dpf1, each stage's reference output kept
+    for name, (dimx, dimy, seed, k, pout) in {"n1_40x40_k8": (40, 40, 5, 8, 0.45), "n1_61x47_k12": (61, 47, 9, 12, 0.5)}.items():
+        xy = synth.make_grid(dimx, dimy, 60, 60, 20, 20, 1806.0, angle_deg=37.0)
+        mps = float(np.float32(xy[1, 0] - xy[0, 0]))
+        dp = synth.synth_candidates(dimx, dimy, seed=seed, k=k, p_out=pout)
+        dp[:, ::7, 2] = 0.05          # below the ncc>0.1 gate (:1010)
+        dp[:3, 5::11, 2] = -3.0       # invalid passes
+        mvn, nclus = ref.cluster_candidates(dp)
+        kmax = int(nclus.max())
+        mvn = mvn[:, :kmax].copy()
+        dpf0 = ref.get_dpf0(mvn, nclus, dimx, dimy, 0.6)
+        ruv = ref.get_ruv_neighbor(xy, dimx, dimy, mps, 3.0)
+        d1, x1, y1 = ref.get_dpf1(dpf0, ruv, mvn, nclus, xy, 16.0, 15.0)
+        np.savez_compressed(
+            os.path.join(OUT, f"{name}.npz"),
+            dp=dp, xyuvav=xy,
+            meter_per_spacing=np.float32(mps), radius=np.float32(3.0), dt=np.float32(16.0), mpp=np.float32(15.0),
+            ruv=ruv, mvn=mvn, nclus=nclus, dpf0=dpf0, dpf1=d1, dx1=x1, dy1=y1)
+        print(f"{name}: kmax={kmax} empty={(nclus == 0).sum()} dpf0<0={(dpf0 < 0).sum()} dpf1<0={(d1 < 0).sum()}")
+
 
 if __name__ == "__main__":
     main()

@@ -30,3 +30,22 @@ def test_qm_golden(oracle, path):
     assert_bits_equal(x, z["dx_out"], "dx")
     assert_bits_equal(y, z["dy_out"], "dy")
     assert (d != z["dpf_in"]).sum() > 0
+
+
+@pytest.mark.parametrize("path", golden_files("n1_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_n1_golden(oracle, path):
+    """N1 (clustering -> dpf0 -> dpf1) stage by stage against the reference's outputs."""
+    z = np.load(path)
+    dimy, dimx = z["dpf0"].shape
+    kmax = z["mvn"].shape[1]
+    mvn, nclus = oracle.cluster_candidates(z["dp"], kmax)
+    assert np.array_equal(nclus, z["nclus"])
+    assert_bits_equal(mvn, z["mvn"], "mvn")
+    dpf0 = oracle.get_dpf0(z["mvn"], z["nclus"], dimx, dimy, 0.6)
+    assert np.array_equal(dpf0, z["dpf0"])
+    ruv = oracle.get_ruv_neighbor(z["xyuvav"], dimx, dimy, float(z["meter_per_spacing"]), float(z["radius"]))
+    assert np.array_equal(ruv, z["ruv"])
+    d, x, y = oracle.get_dpf1(z["dpf0"], ruv, z["mvn"], z["nclus"], z["xyuvav"], float(z["dt"]), float(z["mpp"]))
+    assert np.array_equal(d, z["dpf1"])
+    assert_bits_equal(x, z["dx1"], "dx"); assert_bits_equal(y, z["dy1"], "dy")
+    assert (z["dpf0"] < 0).sum() > (d < 0).sum() > 0

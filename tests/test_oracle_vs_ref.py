@@ -54,3 +54,23 @@ def test_qm_vs_reference(oracle, reference, dims):
     assert b[3][2] == 0
     assert np.array_equal(a[0], b[0])
     assert_bits_equal(a[1], b[1]); assert_bits_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("dims", [(40, 40, 5, 8, 0.45, 37.0), (61, 47, 9, 32, 0.5, -100.0), (90, 70, 2, 16, 0.6, 80.0)])
+def test_n1_vs_reference(oracle, reference, dims):
+    """clustering, dpf0 and dpf1 one by one (MIMC_module.c:994-1263, :1330-1718)"""
+    dimx, dimy, seed, k, pout, ang = dims
+    xy = synth.make_grid(dimx, dimy, 60, 60, 20, 20, 1806.0, angle_deg=ang)
+    mps = float(np.float32(xy[1, 0] - xy[0, 0]))
+    dp = synth.synth_candidates(dimx, dimy, seed=seed, k=k, p_out=pout)
+    dp[:, ::7, 2] = 0.05
+    dp[:3, 5::11, 2] = -3.0
+    a = reference.cluster_candidates(dp)
+    b = oracle.cluster_candidates(dp)
+    assert np.array_equal(a[1], b[1]); assert_bits_equal(a[0], b[0], "mvn")
+    d0 = reference.get_dpf0(a[0], a[1], dimx, dimy, 0.6)
+    assert np.array_equal(d0, oracle.get_dpf0(a[0], a[1], dimx, dimy, 0.6))
+    ruv = reference.get_ruv_neighbor(xy, dimx, dimy, mps, 3.0)
+    ra = reference.get_dpf1(d0, ruv, a[0], a[1], xy, 16.0, 15.0)
+    rb = oracle.get_dpf1(d0, ruv, a[0], a[1], xy, 16.0, 15.0)
+    assert np.array_equal(ra[0], rb[0]); assert_bits_equal(ra[1], rb[1], "dx"); assert_bits_equal(ra[2], rb[2], "dy")
