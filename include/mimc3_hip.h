@@ -113,6 +113,38 @@ int mimc3_qm_pseudosmooth_dev(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_
                               const int32_t *d_nclus, const double *d_xyuvav, int32_t max_sweeps,
                               void *d_work, int32_t *d_sweeps_done, void *stream);
 
+/* ---- N1 (the stages between the 32 matcher passes and the QM update) ------------------------------
+ *      Candidate clustering.  Replaces calc_mean_var_num_dp_cluster (MIMC_module.h:49, MIMC_module.c:994-1130)
+ *      with cluster_euclidian / mark_row (:1133-1222).  dp = the ndp matcher outputs, pass-major
+ *      [ndp][N][3] (flattening of `GMA_float **dp`), 1 <= ndp <= 64.  mvn out = [N][Kmax][5] (mean_u, mean_v,
+ *      var_u, var_v, fraction; padding rows zero), nclus out = [N].  *kmax_seen = the largest cluster count;
+ *      MIMC3_ECAP if it exceeds Kmax (Kmax = ndp is always enough). ------------------------------------ */
+int mimc3_cluster_candidates(mimc3_ctx *ctx, const float *dp, int32_t ndp, int32_t N, int32_t Kmax, float *mvn,
+                             int32_t *nclus, int32_t *kmax_seen);
+int mimc3_cluster_candidates_dev(mimc3_ctx *ctx, const float *d_dp, int32_t ndp, int32_t N, int32_t Kmax,
+                                 float *d_mvn, int32_t *d_nclus, int32_t *d_kmax_seen, void *stream);
+
+/*      Prominent-cluster pick.  Replaces get_dpf0 (MIMC_module.h:52, MIMC_module.c:1224-1263):
+ *      dpf[g] = first cluster whose fraction > min_ratio, else -1. ---------------------------------- */
+int mimc3_get_dpf0(mimc3_ctx *ctx, const float *mvn, const int32_t *nclus, int32_t N, int32_t Kmax, float min_ratio,
+                   int32_t *dpf);
+int mimc3_get_dpf0_dev(mimc3_ctx *ctx, const float *d_mvn, const int32_t *d_nclus, int32_t N, int32_t Kmax,
+                       float min_ratio, int32_t *d_dpf, void *stream);
+
+/*      A-priori-guided fill of the unassigned points.  Replaces get_dpf1 (MIMC_module.h:54,
+ *      MIMC_module.c:1330-1718).  dpf in = dpf0, out = dpf1 ([dimy][dimx]); dpf_dx, dpf_dy out.  dt, mpp = the
+ *      reference's globals `dt` and `param_mimc2.mpp`.  The sweep count is data dependent and unbounded in
+ *      the reference, so even the _dev variant synchronises `stream` once per 8 sweeps to poll the device's
+ *      done flag; d_work must hold mimc3_dpf1_workspace_bytes(dimy*dimx).  sweeps_done (host, may be NULL)
+ *      receives the reference's NOI. -------------------------------------------------------------------- */
+int mimc3_get_dpf1(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,
+                   const int32_t *ruv, int32_t nn, const float *mvn, int32_t Kmax, const int32_t *nclus,
+                   const double *xyuvav, float dt, float mpp, int32_t *sweeps_done);
+int64_t mimc3_dpf1_workspace_bytes(int32_t ngrid);
+int mimc3_get_dpf1_dev(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *d_dpf, float *d_dpf_dx, float *d_dpf_dy,
+                       const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax, const int32_t *d_nclus,
+                       const double *d_xyuvav, float dt, float mpp, void *d_work, int32_t *sweeps_done, void *stream);
+
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */
 int mimc3_ctx_enable_timing(mimc3_ctx *ctx, int32_t on);

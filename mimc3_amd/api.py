@@ -52,6 +52,16 @@ _lib.mimc3_qm_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
 _lib.mimc3_qm_workspace_bytes.restype = C.c_int64
 _lib.mimc3_qm_pseudosmooth_dev.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp,
                                            _vp, C.c_int32, _vp, _vp, _vp]
+_lib.mimc3_cluster_candidates.argtypes = [_vp, _f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _i32p, C.POINTER(C.c_int32)]
+_lib.mimc3_cluster_candidates_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]
+_lib.mimc3_get_dpf0.argtypes = [_vp, _f32p, _i32p, C.c_int32, C.c_int32, C.c_float, _i32p]
+_lib.mimc3_get_dpf0_dev.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, _vp, _vp]
+_lib.mimc3_get_dpf1.argtypes = [_vp, C.c_int32, C.c_int32, _i32p, _f32p, _f32p, _i32p, C.c_int32, _f32p, C.c_int32, _i32p,
+                                _f64p, C.c_float, C.c_float, C.POINTER(C.c_int32)]
+_lib.mimc3_dpf1_workspace_bytes.argtypes = [C.c_int32]
+_lib.mimc3_dpf1_workspace_bytes.restype = C.c_int64
+_lib.mimc3_get_dpf1_dev.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp,
+                                    C.c_float, C.c_float, _vp, C.POINTER(C.c_int32), _vp]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
@@ -193,6 +203,60 @@ class Context:
                                     max_sweeps, d_work, d_sweeps=None, stream=0):
         _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
                                               d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- N1: clustering, dpf0, dpf1 -------------------------------------------------------------
+    def calc_mean_var_num_dp_cluster(self, dp, kmax=None):
+        """calc_mean_var_num_dp_cluster (MIMC_module.c:994-1130). dp [ndp][N][3] -> (mvn [N][kmax][5], nclus [N]).
+        kmax defaults to ndp (always enough); raises Mimc3Error(ECAP) if a point has more clusters than kmax."""
+        dp = np.ascontiguousarray(dp, np.float32)
+        ndp, n, _ = dp.shape
+        kmax = int(kmax or ndp)
+        mvn = np.empty((n, kmax, 5), np.float32)
+        nclus = np.empty(n, np.int32)
+        seen = C.c_int32(0)
+        _check(_lib.mimc3_cluster_candidates(self._h, dp, ndp, n, kmax, mvn, nclus, C.byref(seen)),
+               "calc_mean_var_num_dp_cluster")
+        return mvn, nclus
+
+    def calc_mean_var_num_dp_cluster_dev(self, d_dp, ndp, n, kmax, d_mvn, d_nclus, d_kmax_seen, stream=0):
+        _check(_lib.mimc3_cluster_candidates_dev(self._h, d_dp, ndp, n, kmax, d_mvn, d_nclus, d_kmax_seen, stream),
+               "calc_mean_var_num_dp_cluster_dev")
+
+    def get_dpf0(self, mvn, nclus, dimx, dimy, min_ratio=0.6):
+        """get_dpf0 (MIMC_module.c:1224-1263) -> dpf0 [dimy][dimx]."""
+        mvn = np.ascontiguousarray(mvn, np.float32)
+        dpf = np.empty(dimx * dimy, np.int32)
+        _check(_lib.mimc3_get_dpf0(self._h, mvn, np.ascontiguousarray(nclus, np.int32), dimx * dimy, mvn.shape[1],
+                                   min_ratio, dpf), "get_dpf0")
+        return dpf.reshape(dimy, dimx)
+
+    def get_dpf0_dev(self, d_mvn, d_nclus, n, kmax, min_ratio, d_dpf, stream=0):
+        _check(_lib.mimc3_get_dpf0_dev(self._h, d_mvn, d_nclus, n, kmax, min_ratio, d_dpf, stream), "get_dpf0_dev")
+
+    def get_dpf1(self, dpf0, ruv, mvn, nclus, xyuvav, dt, mpp):
+        """get_dpf1 (MIMC_module.c:1330-1718). Returns (dpf1, dx, dy, sweeps); inputs untouched."""
+        dimy, dimx = dpf0.shape
+        d = np.array(dpf0, np.int32, order="C")
+        x = np.empty((dimy, dimx), np.float32)
+        y = np.empty((dimy, dimx), np.float32)
+        ruv = np.ascontiguousarray(ruv, np.int32)
+        mvn = np.ascontiguousarray(mvn, np.float32)
+        sw = C.c_int32(0)
+        _check(_lib.mimc3_get_dpf1(self._h, dimy, dimx, d.reshape(-1), x.reshape(-1), y.reshape(-1), ruv, ruv.shape[0],
+                                   mvn, mvn.shape[1], np.ascontiguousarray(nclus, np.int32),
+                                   np.ascontiguousarray(xyuvav, np.float64), dt, mpp, C.byref(sw)), "get_dpf1")
+        return d, x, y, sw.value
+
+    def dpf1_workspace_bytes(self, ngrid):
+        return int(_lib.mimc3_dpf1_workspace_bytes(ngrid))
+
+    def get_dpf1_dev(self, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus, d_xyuvav, dt, mpp, d_work,
+                     stream=0):
+        """Device-resident get_dpf1; synchronises `stream` once per 8 sweeps. Returns the sweep count."""
+        sw = C.c_int32(0)
+        _check(_lib.mimc3_get_dpf1_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus, d_xyuvav,
+                                       dt, mpp, d_work, C.byref(sw), stream), "get_dpf1_dev")
+        return sw.value
 
     # -- kernel selection ---------------------------------------------------------------------
     def set_path(self, mode):

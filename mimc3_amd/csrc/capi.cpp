@@ -12,6 +12,7 @@
 #include "host_util.h"
 #include "match_kernel.h"
 #include "qm_kernel.h"
+#include "n1_kernel.h"
 
 namespace mimc3 {
 static thread_local std::string g_err;
@@ -66,6 +67,7 @@ struct mimc3_ctx {
     int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
     DevBuf qm_io, qm_work;              // QM staging / workspace
+    DevBuf n1_io, n1_work;              // clustering / dpf0 / dpf1 staging and workspace
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -111,6 +113,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fpl0.release(); c->fpl1.release(); c->hpl0.release(); c->hpl1.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
+    c->n1_io.release(); c->n1_work.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -415,5 +418,152 @@ extern "C" int mimc3_qm_pseudosmooth(mimc3_ctx *c, int32_t dimy, int32_t dimx, i
     HIP_TRY(hipMemcpyAsync(&sw, b + o_swp, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (sweeps_done) *sweeps_done = sw;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N1: candidate clustering, dpf0, dpf1
+// ---------------------------------------------------------------------------------------------
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" int mimc3_cluster_candidates_dev(mimc3_ctx *c, const float *d_dp, int32_t ndp, int32_t N, int32_t Kmax,
+                                            float *d_mvn, int32_t *d_nclus, int32_t *d_kmax_seen, void *stream)
+{
+    if (!c || !d_dp || !d_mvn || !d_nclus || !d_kmax_seen || N <= 0 || Kmax <= 0 || ndp <= 0 || ndp > mimc3::kCluMaxPasses)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_cluster_candidates_dev: bad argument (1 <= ndp <= 64)");
+    HIP_TRY(hipSetDevice(c->device));
+    mimc3::ClusterArgs a{};
+    a.dp = d_dp; a.ndp = ndp; a.N = N; a.Kmax = Kmax; a.mvn = d_mvn; a.nclus = d_nclus; a.kmax_seen = d_kmax_seen;
+    hipError_t e = mimc3::launch_cluster(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "cluster kernel launch");
+    return 0;
+}
+
+extern "C" int mimc3_cluster_candidates(mimc3_ctx *c, const float *dp, int32_t ndp, int32_t N, int32_t Kmax, float *mvn,
+                                        int32_t *nclus, int32_t *kmax_seen)
+{
+    if (!c || !dp || !mvn || !nclus || N <= 0 || Kmax <= 0 || ndp <= 0 || ndp > mimc3::kCluMaxPasses)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_cluster_candidates: bad argument (1 <= ndp <= 64)");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t b_dp = 12 * (size_t)ndp * N, b_mvn = 20 * (size_t)N * Kmax, b_ncl = 4 * (size_t)N;
+    const size_t o_dp = 0, o_mvn = o_dp + al256(b_dp), o_ncl = o_mvn + al256(b_mvn), o_k = o_ncl + al256(b_ncl), total = o_k + 256;
+    HIP_TRY(c->n1_io.reserve(total));
+    char *b = static_cast<char *>(c->n1_io.p);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_dp, dp, b_dp, hipMemcpyHostToDevice, s));
+    int rc = mimc3_cluster_candidates_dev(c, reinterpret_cast<const float *>(b + o_dp), ndp, N, Kmax, reinterpret_cast<float *>(b + o_mvn),
+                                          reinterpret_cast<int32_t *>(b + o_ncl), reinterpret_cast<int32_t *>(b + o_k), s);
+    if (rc) return rc;
+    int32_t k = 0;
+    HIP_TRY(hipMemcpyAsync(mvn, b + o_mvn, b_mvn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(nclus, b + o_ncl, b_ncl, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&k, b + o_k, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (kmax_seen) *kmax_seen = k;
+    if (k > Kmax) return mimc3::fail(MIMC3_ECAP, "mimc3_cluster_candidates: a grid point has more clusters than Kmax");
+    return 0;
+}
+
+extern "C" int mimc3_get_dpf0_dev(mimc3_ctx *c, const float *d_mvn, const int32_t *d_nclus, int32_t N, int32_t Kmax,
+                                  float min_ratio, int32_t *d_dpf, void *stream)
+{
+    if (!c || !d_mvn || !d_nclus || !d_dpf || N <= 0 || Kmax <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf0_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = mimc3::launch_dpf0(d_mvn, d_nclus, N, Kmax, min_ratio, d_dpf, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "dpf0 kernel launch");
+    return 0;
+}
+
+extern "C" int mimc3_get_dpf0(mimc3_ctx *c, const float *mvn, const int32_t *nclus, int32_t N, int32_t Kmax, float min_ratio,
+                              int32_t *dpf)
+{
+    if (!c || !mvn || !nclus || !dpf || N <= 0 || Kmax <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf0: bad argument");
+    for (int32_t i = 0; i < N; ++i)
+        if (nclus[i] < 0 || nclus[i] > Kmax) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf0: cluster count exceeds Kmax");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t b_mvn = 20 * (size_t)N * Kmax, b_n = 4 * (size_t)N;
+    const size_t o_mvn = 0, o_ncl = al256(b_mvn), o_dpf = o_ncl + al256(b_n), total = o_dpf + al256(b_n);
+    HIP_TRY(c->n1_io.reserve(total));
+    char *b = static_cast<char *>(c->n1_io.p);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_mvn, mvn, b_mvn, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_ncl, nclus, b_n, hipMemcpyHostToDevice, s));
+    int rc = mimc3_get_dpf0_dev(c, reinterpret_cast<const float *>(b + o_mvn), reinterpret_cast<const int32_t *>(b + o_ncl), N, Kmax,
+                                min_ratio, reinterpret_cast<int32_t *>(b + o_dpf), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dpf, b + o_dpf, b_n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int64_t mimc3_dpf1_workspace_bytes(int32_t ngrid) { return ngrid > 0 ? mimc3::dpf1_workspace_bytes(ngrid) : 0; }
+
+extern "C" int mimc3_get_dpf1_dev(mimc3_ctx *c, int32_t dimy, int32_t dimx, int32_t *d_dpf, float *d_dpf_dx, float *d_dpf_dy,
+                                  const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax, const int32_t *d_nclus,
+                                  const double *d_xyuvav, float dt, float mpp, void *d_work, int32_t *sweeps_done, void *stream)
+{
+    if (!c || !d_dpf || !d_dpf_dx || !d_dpf_dy || !d_ruv || !d_mvn || !d_nclus || !d_xyuvav || !d_work || dimx <= 0 ||
+        dimy <= 0 || nn <= 0 || Kmax <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf1_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    mimc3::Dpf1Args a{};
+    a.dimy = dimy; a.dimx = dimx; a.N = dimx * dimy;
+    a.dpf = d_dpf; a.dx = d_dpf_dx; a.dy = d_dpf_dy; a.ruv = d_ruv; a.nn = nn; a.mvn = d_mvn; a.Kmax = Kmax;
+    a.nclus = d_nclus; a.xyuvav = d_xyuvav;
+    a.factor = (float)(1.0 / 365.0 * dt / mpp);                     // MIMC_module.c:1391
+    float tw = 0.5; tw -= 0.02;                                     // :1386, :1395 (f32 variable, f64 constant)
+    a.thres_weight = tw;
+    mimc3::dpf1_carve(a, d_work);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = mimc3::launch_dpf1_init(a, s);
+    if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 init launch");
+    // the reference's sweep count is data dependent and unbounded: enqueue batches, poll the device's done flag
+    int32_t st[mimc3::kD1Words] = {0};
+    for (;;) {
+        e = mimc3::launch_dpf1_sweeps(a, 8, s);
+        if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 sweep launch");
+        HIP_TRY(hipMemcpyAsync(st, a.state, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (st[mimc3::kD1Done]) break;
+    }
+    e = mimc3::launch_dpf1_finish(a, s);
+    if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 finish launch");
+    if (sweeps_done) *sweeps_done = st[mimc3::kD1Sweeps];
+    return 0;
+}
+
+extern "C" int mimc3_get_dpf1(mimc3_ctx *c, int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,
+                              const int32_t *ruv, int32_t nn, const float *mvn, int32_t Kmax, const int32_t *nclus,
+                              const double *xyuvav, float dt, float mpp, int32_t *sweeps_done)
+{
+    if (!c || !dpf || !dpf_dx || !dpf_dy || !ruv || !mvn || !nclus || !xyuvav || dimx <= 0 || dimy <= 0 || nn <= 0 || Kmax <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf1: bad argument");
+    const size_t N = (size_t)dimx * dimy;
+    for (size_t i = 0; i < N; ++i)
+        if (nclus[i] < 0 || nclus[i] > Kmax || dpf[i] >= nclus[i])
+            return mimc3::fail(MIMC3_EINVAL, "mimc3_get_dpf1: cluster count/id out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t o_dpf = 0, o_dx = o_dpf + al256(4 * N), o_dy = o_dx + al256(4 * N), o_ruv = o_dy + al256(4 * N),
+                 o_mvn = o_ruv + al256(8 * (size_t)nn), o_ncl = o_mvn + al256(20 * N * Kmax), o_xy = o_ncl + al256(4 * N),
+                 total = o_xy + al256(48 * N);
+    HIP_TRY(c->n1_io.reserve(total));
+    HIP_TRY(c->n1_work.reserve((size_t)mimc3::dpf1_workspace_bytes((int32_t)N)));
+    char *b = static_cast<char *>(c->n1_io.p);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_dpf, dpf, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_ruv, ruv, 8 * (size_t)nn, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_mvn, mvn, 20 * N * Kmax, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_ncl, nclus, 4 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + o_xy, xyuvav, 48 * N, hipMemcpyHostToDevice, s));
+    int rc = mimc3_get_dpf1_dev(c, dimy, dimx, reinterpret_cast<int32_t *>(b + o_dpf), reinterpret_cast<float *>(b + o_dx),
+                                reinterpret_cast<float *>(b + o_dy), reinterpret_cast<const int32_t *>(b + o_ruv), nn,
+                                reinterpret_cast<const float *>(b + o_mvn), Kmax, reinterpret_cast<const int32_t *>(b + o_ncl),
+                                reinterpret_cast<const double *>(b + o_xy), dt, mpp, c->n1_work.p, sweeps_done, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dpf, b + o_dpf, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dpf_dx, b + o_dx, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dpf_dy, b + o_dy, 4 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
