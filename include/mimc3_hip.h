@@ -134,7 +134,7 @@ int mimc3_get_dpf0_dev(mimc3_ctx *ctx, const float *d_mvn, const int32_t *d_nclu
 /*      A-priori-guided fill of the unassigned points.  Replaces get_dpf1 (MIMC_module.h:54,
  *      MIMC_module.c:1330-1718).  dpf in = dpf0, out = dpf1 ([dimy][dimx]); dpf_dx, dpf_dy out.  dt, mpp = the
  *      reference's globals `dt` and `param_mimc2.mpp`.  The sweep count is data dependent and unbounded in
- *      the reference, so even the _dev variant synchronises `stream` once per 8 sweeps to poll the device's
+ *      the reference, so even the _dev variant synchronises `stream` once per 32 sweeps to poll the device's
  *      done flag; d_work must hold mimc3_dpf1_workspace_bytes(dimy*dimx).  sweeps_done (host, may be NULL)
  *      receives the reference's NOI. -------------------------------------------------------------------- */
 int mimc3_get_dpf1(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *dpf, float *dpf_dx, float *dpf_dy,

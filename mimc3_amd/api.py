@@ -252,7 +252,7 @@ class Context:
 
     def get_dpf1_dev(self, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus, d_xyuvav, dt, mpp, d_work,
                      stream=0):
-        """Device-resident get_dpf1; synchronises `stream` once per 8 sweeps. Returns the sweep count."""
+        """Device-resident get_dpf1; synchronises `stream` once per 32 sweeps. Returns the sweep count."""
         sw = C.c_int32(0)
         _check(_lib.mimc3_get_dpf1_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus, d_xyuvav,
                                        dt, mpp, d_work, C.byref(sw), stream), "get_dpf1_dev")

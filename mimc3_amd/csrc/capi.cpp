@@ -521,7 +521,7 @@ extern "C" int mimc3_get_dpf1_dev(mimc3_ctx *c, int32_t dimy, int32_t dimx, int3
     // the reference's sweep count is data dependent and unbounded: enqueue batches, poll the device's done flag
     int32_t st[mimc3::kD1Words] = {0};
     for (;;) {
-        e = mimc3::launch_dpf1_sweeps(a, 8, s);
+        e = mimc3::launch_dpf1_sweeps(a, 32, s);
         if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 sweep launch");
         HIP_TRY(hipMemcpyAsync(st, a.state, sizeof(st), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

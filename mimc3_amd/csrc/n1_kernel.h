@@ -22,7 +22,9 @@ hipError_t launch_dpf0(const float *mvn, const int32_t *nclus, int32_t N, int32_
                        int32_t *dpf, hipStream_t stream);
 
 // dpf1 state words (device)
-enum { kD1ThresNum = 0, kD1Done = 1, kD1Sweeps = 2, kD1Processed = 3, kD1Unprocessed = 4, kD1Words = 8 };
+enum { kD1ThresNum = 0, kD1Done = 1, kD1Sweeps = 2, kD1Tally = 4 /* u64: ticket | processed | unprocessed */, kD1Words = 8 };
+constexpr int kD1SweepThreads = 256;
+constexpr int kD1MaxNeighbours = 4096;   // get_ruv_neighbor's capacity in this library
 
 struct Dpf1Args {
     int32_t dimy, dimx, N;
@@ -37,13 +39,16 @@ struct Dpf1Args {
     float factor;            // (float)(1.0/365.0*dt/mpp)          (:1391)
     float thres_weight;      // (float)((double)0.5f - 0.02)        (:1386-1395)
     // workspace (carved by the launchers)
-    float *bx, *by, *noi;
+    float4 *plane[2];        // [N] (dx, dy, noi, v3), ping-ponged by the sweeps
+    float4 *rec;             // [N] (v4, v5, w2, -)
+    float *bx, *by;          // [N] smoothing buffers
+    int4 *ktab;              // [nn] (du, dv, |d| bits, -)
     int32_t *state;          // [kD1Words]
 };
 int64_t dpf1_workspace_bytes(int32_t n);
 void dpf1_carve(Dpf1Args &a, void *work);
 hipError_t launch_dpf1_init(const Dpf1Args &a, hipStream_t stream);
-// `count` x (sweep, commit, decide); every kernel returns at once when state[kD1Done] is set
+// `count` sweeps; each returns at once when state[kD1Done] is set
 hipError_t launch_dpf1_sweeps(const Dpf1Args &a, int count, hipStream_t stream);
 // 3x3 smoothing + snap to the nearest cluster (:1623-1706)
 hipError_t launch_dpf1_finish(const Dpf1Args &a, hipStream_t stream);

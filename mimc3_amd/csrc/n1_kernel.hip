@@ -12,7 +12,7 @@
 // the frontier), and each cluster's sums are accumulated in candidate order (f32, like the reference).
 // A block stages 64 consecutive grid points of every pass through LDS so that the pass-major candidate
 // planes are read coalesced.  dpf1 is one thread per grid point per sweep; the sweep/level control of the
-// reference (:1383-1621) runs on the device in a one-thread decide kernel, the host only polls "done".
+// reference (:1383-1621) runs on the device in the sweep kernel's last block, the host only polls "done".
 //
 // Arithmetic follows the reference's C promotions literally (f32 products, sqrt() in f64 rounded to f32,
 // one f32/f64 quotient), compiled with -ffp-contract=off.  expf() is taken as the f32 rounding of the f64
@@ -120,130 +120,181 @@ __global__ __launch_bounds__(256) void dpf0_kernel(const float *__restrict__ mvn
 
 __device__ __forceinline__ float sqrt_f(float s) { return (float)sqrt((double)s); }  // C: sqrt(float) is the f64 sqrt
 
+// Per-point terms of get_dpf1's neighbour table (:1421-1448) that depend only on the neighbour h itself:
+//   v5 = |a-priori(h)|, w2 = 1/(1+expf(5-v5)) are fixed; v4 = |dp(h)|, v3 = v4/|a-priori(h)| and v6 = noi(h) change
+//   only when h receives a value.  They are kept per point instead of being recomputed per (g,k) pair:
+//   field plane P[h] = (dx, dy, noi, v3)  -- ping-ponged, one 16-byte gather per neighbour
+//   rec[h]          = (v4, v5, w2, -)     -- in place
+// A sweep is latency bound (the whole grid is resident at once, so a launch lasts as long as one thread's chain
+// of dependent loads): the neighbour offsets sit in LDS and the gathers are unconditional so that the compiler
+// keeps several in flight.
+__device__ __forceinline__ double apriori_mag(const Dpf1Args &a, int h, float &v5)
+{
+    const float a0 = (float)(a.xyuvav[6 * (size_t)h + 4]) * a.factor;
+    const float a1 = -(float)(a.xyuvav[6 * (size_t)h + 5]) * a.factor;
+    const float aa = a0 * a0 + a1 * a1;
+    v5 = sqrt_f(aa);
+    return sqrt((double)aa);
+}
+
 __global__ __launch_bounds__(256) void dpf1_init(Dpf1Args a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         a.state[kD1ThresNum] = a.nn - 1;
         a.state[kD1Done] = (a.nn - 1 < 3) ? 1 : 0;
-        a.state[kD1Sweeps] = 0; a.state[kD1Processed] = 0; a.state[kD1Unprocessed] = 0;
+        a.state[kD1Sweeps] = 0; a.state[kD1Tally] = 0; a.state[kD1Tally + 1] = 0;
+    }
+    if (i < a.nn) {
+        const int ou = a.ruv[2 * i], ov = a.ruv[2 * i + 1];
+        const float d0 = (float)ou, d1 = (float)ov;
+        a.ktab[i] = make_int4(ou, ov, __float_as_int(sqrt_f(d0 * d0 + d1 * d1)), 0);   // :1466
     }
     if (i >= a.N) return;
     const float nanv = __builtin_nanf("");
     const int id = a.dpf[i];
-    a.noi[i] = 1.0f;
-    if (id >= 0) { a.dx[i] = a.mvn[((size_t)i * a.Kmax + id) * 5]; a.dy[i] = a.mvn[((size_t)i * a.Kmax + id) * 5 + 1]; }   // :1352-1365
-    else { a.dx[i] = nanv; a.dy[i] = nanv; }
-    a.bx[i] = nanv; a.by[i] = nanv;
+    float x = nanv, y = nanv;
+    if (id >= 0) { x = a.mvn[((size_t)i * a.Kmax + id) * 5]; y = a.mvn[((size_t)i * a.Kmax + id) * 5 + 1]; }   // :1352-1365
+    float v5;
+    const double sq = apriori_mag(a, i, v5);
+    const float v4 = sqrt_f(x * x + y * y);
+    const float e = (float)exp((double)(-v5 + 5.0f));                        // expf, see the header note
+    a.plane[0][i] = make_float4(x, y, 1.0f, (float)((double)v4 / sq));
+    a.rec[i] = make_float4(v4, v5, 1.0f / (1.0f + e) / 1.0f, 0.0f);
 }
 
-struct Nb { float wc, v3, v4, v5, v6; };
-
-// one neighbour's terms (:1421-1448, :1466-1470); false if it does not count
-__device__ __forceinline__ bool neighbour(const Dpf1Args &a, int cu, int cv, int k, float dpe0, float dpe1, float mag_dpe, Nb &o)
+// One Jacobi sweep (:1399-1547) in ONE kernel: the field is ping-ponged (sweep s reads plane s&1 and writes the
+// other one for every point), so the reference's "compute into buffers, then commit" (:1533-1545) needs no second
+// pass; the block that finishes last runs the level control of :1383-1621 for the next launch.
+__device__ __forceinline__ bool dpf1_point(const Dpf1Args &a, const float4 *__restrict__ src, const int4 *kt, int g, int thres_num,
+                                           float4 &out)
 {
-    const int ou = a.ruv[2 * k], ov = a.ruv[2 * k + 1];
-    const int u = cu + ou, w = cv + ov;
-    if (u < 0 || u >= a.dimx || w < 0 || w >= a.dimy) return false;
-    const int h = w * a.dimx + u;
-    const float n0 = a.dx[h], n1 = a.dy[h];
-    if (isnan(n0 + n1)) return false;
-    const float a0 = (float)(a.xyuvav[6 * (size_t)h + 4]) * a.factor;
-    const float a1 = -(float)(a.xyuvav[6 * (size_t)h + 5]) * a.factor;
-    const float aa = a0 * a0 + a1 * a1;
-    o.v4 = sqrt_f(n0 * n0 + n1 * n1);
-    o.v5 = sqrt_f(aa);
-    o.v6 = a.noi[h];
-    o.v3 = (float)((double)o.v4 / sqrt((double)aa));
-    const float d0 = (float)ou, d1 = (float)ov;
-    const float mag = sqrt_f(d0 * d0 + d1 * d1);
-    float wc = (dpe0 * d0 + dpe1 * d1) / (mag_dpe * mag);
-    o.wc = wc > 0 ? wc : -wc;
-    return true;
-}
-
-__global__ __launch_bounds__(256) void dpf1_sweep(Dpf1Args a)
-{
-    if (a.state[kD1Done]) return;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.N) return;
-    if (!(isnan(a.dx[g] + a.dy[g]) && a.nclus[g] != 0)) return;              // :1406
-    const int thres_num = a.state[kD1ThresNum];
     const float tw = a.thres_weight;
     const int cv = g / a.dimx, cu = g - cv * a.dimx;
     const float dpe0 = (float)(a.xyuvav[6 * (size_t)g + 4] * (double)a.factor);     // :1411-1413
     const float dpe1 = (float)(-a.xyuvav[6 * (size_t)g + 5] * (double)a.factor);
     const float mag_dpe = sqrt_f(dpe0 * dpe0 + dpe1 * dpe1);
 
-    // pass 1: count, and the extremes of |dp|/|a-priori| among the direction-weighted neighbours (:1458-1489)
+    // pass 1: count (:1452) and the extremes of |dp|/|a-priori| among the direction-weighted neighbours (:1458-1489).
+    // Gathers are issued eight at a time ahead of their use: a sweep lasts as long as one thread's chain of loads.
+    constexpr int B = 8;
     int num = 0, id_max = 0, id_min = 0;
     float w_min = 1E+37f, w_max = -1E+37f;
-    Nb nb;
-    for (int k = 0; k < a.nn; k++) {
-        if (!neighbour(a, cu, cv, k, dpe0, dpe1, mag_dpe, nb)) continue;
-        if (nb.wc >= tw) {
-            if (nb.v3 > w_max) { w_max = nb.v3; id_max = num; }
-            if (nb.v3 < w_min) { w_min = nb.v3; id_min = num; }
+    for (int k0 = 0; k0 < a.nn; k0 += B) {
+        int4 t[B]; float4 f[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            t[j] = kt[min(k0 + j, a.nn - 1)];
+            const int u = cu + t[j].x, w = cv + t[j].y;
+            const bool in = (k0 + j < a.nn) & (u >= 0) & (u < a.dimx) & (w >= 0) & (w < a.dimy);
+            f[j] = src[in ? w * a.dimx + u : g];                             // g itself is NaN: counts as absent
         }
-        num++;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (isnan(f[j].x + f[j].y)) continue;
+            float wc = (dpe0 * (float)t[j].x + dpe1 * (float)t[j].y) / (mag_dpe * __int_as_float(t[j].z));
+            wc = wc > 0 ? wc : -wc;
+            if (wc >= tw) {
+                if (f[j].w > w_max) { w_max = f[j].w; id_max = num; }
+                if (f[j].w < w_min) { w_min = f[j].w; id_min = num; }
+            }
+            num++;
+        }
     }
-    if (num < thres_num) return;                                             // :1452
+    if (num < thres_num) return false;
 
     // pass 2: the weighted sums, neighbours in the same order (:1497-1510)
     float s_w = 0.0f, s_wdp = 0.0f, s_wdpe = 0.0f, s_noi = 0.0f;
     int i = 0;
-    for (int k = 0; k < a.nn; k++) {
-        if (!neighbour(a, cu, cv, k, dpe0, dpe1, mag_dpe, nb)) continue;
-        const float v2 = (nb.wc >= tw && i != id_max && i != id_min) ? nb.wc : 0.0f;
-        const float e = (float)exp((double)(-nb.v5 + 5.0f));
-        const float w2 = 1.0f / (1.0f + e) / 1.0f;
-        s_w += v2;
-        s_wdp += v2 * w2 * nb.v4 / nb.v6;
-        s_wdpe += v2 * w2 * nb.v5 / nb.v6;
-        s_noi += nb.v6;
-        i++;
-    }
-    if (s_w >= 1.0f) {                                                       // :1512-1526
-        const float fm = s_wdp / s_wdpe;
-        a.bx[g] = dpe0 * fm; a.by[g] = dpe1 * fm;
-        a.noi[g] = s_noi / (float)num + 1.0f;
-        atomicAdd(&a.state[kD1Processed], 1);
-    }
-}
-
-__global__ __launch_bounds__(256) void dpf1_commit(Dpf1Args a)
-{
-    if (a.state[kD1Done]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool un = false;
-    if (i < a.N) {
-        float x = a.dx[i], y = a.dy[i];
-        const float px = a.bx[i], py = a.by[i];
-        if (!isnan(px) && !isnan(py)) {                                      // :1533-1545
-            const float nanv = __builtin_nanf("");
-            x = px; y = py;
-            a.dx[i] = x; a.dy[i] = y; a.bx[i] = nanv; a.by[i] = nanv;
+    for (int k0 = 0; k0 < a.nn; k0 += B) {
+        int4 t[B]; float4 f[B], r[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            t[j] = kt[min(k0 + j, a.nn - 1)];
+            const int u = cu + t[j].x, w = cv + t[j].y;
+            const bool in = (k0 + j < a.nn) & (u >= 0) & (u < a.dimx) & (w >= 0) & (w < a.dimy);
+            const int h = in ? w * a.dimx + u : g;
+            f[j] = src[h];
+            r[j] = a.rec[h];                                                 // v4, v5, w2
         }
-        un = (isnan(x) || isnan(y)) && a.nclus[i] != 0;                      // :1551-1560
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (isnan(f[j].x + f[j].y)) continue;
+            float wc = (dpe0 * (float)t[j].x + dpe1 * (float)t[j].y) / (mag_dpe * __int_as_float(t[j].z));
+            wc = wc > 0 ? wc : -wc;
+            const float v2 = (wc >= tw && i != id_max && i != id_min) ? wc : 0.0f;
+            s_w += v2;
+            s_wdp += v2 * r[j].z * r[j].x / f[j].z;
+            s_wdpe += v2 * r[j].z * r[j].y / f[j].z;
+            s_noi += f[j].z;
+            i++;
+        }
     }
-    const uint64_t b = __ballot(un);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&a.state[kD1Unprocessed], __builtin_popcountll(b));
+    if (!(s_w >= 1.0f)) return false;                                        // :1512
+    const float fm = s_wdp / s_wdpe;
+    const float ox = dpe0 * fm, oy = dpe1 * fm;
+    float v5;
+    const double sq = apriori_mag(a, g, v5);
+    const float v4 = sqrt_f(ox * ox + oy * oy);
+    out = make_float4(ox, oy, s_noi / (float)num + 1.0f, (float)((double)v4 / sq));
+    return true;
 }
 
-// control flow of :1383-1621 after one sweep + commit
-__global__ void dpf1_decide(Dpf1Args a)
+__global__ __launch_bounds__(kD1SweepThreads) void dpf1_sweep(Dpf1Args a)
 {
+    extern __shared__ int4 kt[];                                             // [nn] (du, dv, |d|)
     int32_t *st = a.state;
     if (st[kD1Done]) return;
-    st[kD1Sweeps] += 1;
-    if (st[kD1Processed] == 0) {
-        // the inner while ends; thres_weight is now 0.48 < 0.5 so the middle while ends too: next level
-        const int un = st[kD1Unprocessed];
-        st[kD1ThresNum] -= 1;
-        if (un == 0 || st[kD1ThresNum] < 3) st[kD1Done] = 1;
+    for (int k = threadIdx.x; k < a.nn; k += blockDim.x) kt[k] = a.ktab[k];
+    __syncthreads();
+    const int par = st[kD1Sweeps] & 1;
+    const float4 *src = a.plane[par];
+    float4 *dst = a.plane[par ^ 1];
+    const int thres_num = st[kD1ThresNum];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    bool proc = false, un = false;
+    if (g < a.N) {
+        float4 f = src[g];
+        const bool open = a.nclus[g] != 0;
+        if (open && isnan(f.x + f.y)) {                                      // :1406
+            float4 nf;
+            if (dpf1_point(a, src, kt, g, thres_num, nf)) {
+                proc = true;                                                 // :1526 counts it even if the value is NaN
+                if (!isnan(nf.x) && !isnan(nf.y)) {                          // :1533-1545
+                    f = nf;
+                    a.rec[g].x = sqrt_f(nf.x * nf.x + nf.y * nf.y);          // own v4; nobody reads it in this sweep
+                } else f.z = nf.z;                                           // noi is written unconditionally (:1524)
+            }
+        }
+        dst[g] = f;
+        un = open && (isnan(f.x) || isnan(f.y));                             // :1551-1560
     }
-    st[kD1Processed] = 0;
-    st[kD1Unprocessed] = 0;
+    // one packed atomic per block: ticket (16 bits) | processed (24) | unprocessed (24).  No fence: the last
+    // block consumes only the tally itself, the field is consumed by the next launch.
+    const unsigned long long np = (unsigned)__syncthreads_count(proc), nu = (unsigned)__syncthreads_count(un);
+    if (threadIdx.x != 0) return;
+    unsigned long long *tally = reinterpret_cast<unsigned long long *>(st + kD1Tally);
+    const unsigned long long mine = 1ull | (np << 16) | (nu << 40);
+    const unsigned long long seen = atomicAdd(tally, mine) + mine;
+    if ((seen & 0xFFFF) != gridDim.x) return;
+    // last block out: control flow of :1383-1621 after this sweep
+    const unsigned processed = (unsigned)(seen >> 16) & 0xFFFFFF, unproc = (unsigned)(seen >> 40);
+    st[kD1Sweeps] += 1;
+    if (processed == 0) {
+        // the inner while ends; thres_weight is 0.48 < 0.5 by now, so the middle while ends too: next level
+        st[kD1ThresNum] -= 1;
+        if (unproc == 0 || st[kD1ThresNum] < 3) st[kD1Done] = 1;
+    }
+    *tally = 0;
+}
+
+// the field after the last sweep -> dx, dy
+__global__ __launch_bounds__(256) void dpf1_settle(Dpf1Args a)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.N) return;
+    const float4 f = a.plane[a.state[kD1Sweeps] & 1][g];
+    a.dx[g] = f.x; a.dy[g] = f.y;
 }
 
 __global__ __launch_bounds__(256) void dpf1_smooth(Dpf1Args a)
@@ -307,38 +358,42 @@ hipError_t launch_dpf0(const float *mvn, const int32_t *nclus, int32_t N, int32_
     return hipGetLastError();
 }
 
-int64_t dpf1_workspace_bytes(int32_t n) { return 3 * al256(4 * (int64_t)n) + 256; }
+int64_t dpf1_workspace_bytes(int32_t n) { return 2 * al256(4 * (int64_t)n) + 3 * al256(16 * (int64_t)n) + 16 * kD1MaxNeighbours + 256; }
 
 void dpf1_carve(Dpf1Args &a, void *work)
 {
     char *b = static_cast<char *>(work);
-    const int64_t s = al256(4 * (int64_t)a.N);
+    const int64_t s4 = al256(4 * (int64_t)a.N), s16 = al256(16 * (int64_t)a.N);
+    a.plane[0] = reinterpret_cast<float4 *>(b);
+    a.plane[1] = reinterpret_cast<float4 *>(b + s16);
+    a.rec = reinterpret_cast<float4 *>(b + 2 * s16);
+    b += 3 * s16;
     a.bx = reinterpret_cast<float *>(b);
-    a.by = reinterpret_cast<float *>(b + s);
-    a.noi = reinterpret_cast<float *>(b + 2 * s);
-    a.state = reinterpret_cast<int32_t *>(b + 3 * s);
+    a.by = reinterpret_cast<float *>(b + s4);
+    b += 2 * s4;
+    a.ktab = reinterpret_cast<int4 *>(b);
+    a.state = reinterpret_cast<int32_t *>(b + 16 * kD1MaxNeighbours);
 }
 
 hipError_t launch_dpf1_init(const Dpf1Args &a, hipStream_t stream)
 {
+    if (a.nn > kD1MaxNeighbours) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dpf1_init, dim3((a.N + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_dpf1_sweeps(const Dpf1Args &a, int count, hipStream_t stream)
 {
-    const dim3 grid((a.N + 255) / 256), block(256);
-    for (int s = 0; s < count; s++) {
-        hipLaunchKernelGGL(dpf1_sweep, grid, block, 0, stream, a);
-        hipLaunchKernelGGL(dpf1_commit, grid, block, 0, stream, a);
-        hipLaunchKernelGGL(dpf1_decide, dim3(1), dim3(1), 0, stream, a);
-    }
+    const dim3 grid((a.N + kD1SweepThreads - 1) / kD1SweepThreads), block(kD1SweepThreads);
+    if (grid.x > 0xFFFF || a.N >= (1 << 24)) return hipErrorInvalidValue;     // tally field widths
+    for (int s = 0; s < count; s++) hipLaunchKernelGGL(dpf1_sweep, grid, block, sizeof(int4) * (size_t)a.nn, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_dpf1_finish(const Dpf1Args &a, hipStream_t stream)
 {
     const dim3 grid((a.N + 255) / 256), block(256);
+    hipLaunchKernelGGL(dpf1_settle, grid, block, 0, stream, a);
     hipLaunchKernelGGL(dpf1_smooth, grid, block, 0, stream, a);
     hipLaunchKernelGGL(dpf1_snap, grid, block, 0, stream, a);
     return hipGetLastError();
