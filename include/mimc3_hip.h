@@ -145,6 +145,23 @@ int mimc3_get_dpf1_dev(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *d_dp
                        const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax, const int32_t *d_nclus,
                        const double *d_xyuvav, float dt, float mpp, void *d_work, int32_t *sweeps_done, void *stream);
 
+/* ---- N2: image pre-filter.  Replaces GMA_float_conv2 (MIMC_module.h:67, MIMC_module.c:2517-2585): correlation
+ *      with a kh x kw kernel (row-major, at most 81 taps) over the interior, a null DN poisoning its stencil,
+ *      then `out -= min-1` / poisoned -> 0.  `out` [H][W] is IN/OUT exactly as in the reference: its border
+ *      rows/columns are never written by the stencil but take part in the minimum and (right-hand columns) in
+ *      the shift, so pass the buffer the reference would have (a fresh GMA_float_create plane: zeros).
+ *      _dev: d_scratch = 4 bytes of device memory; enqueues on `stream`, no sync. ---------------------- */
+int mimc3_float_conv2(mimc3_ctx *ctx, const float *in, int32_t H, int32_t W, const float *kernel, int32_t kh,
+                      int32_t kw, float *out);
+int mimc3_float_conv2_dev(mimc3_ctx *ctx, const float *d_in, int32_t H, int32_t W, const float *kernel /*host*/,
+                          int32_t kh, int32_t kw, float *d_out, void *d_scratch, void *stream);
+/*      Filter the context's resident pair on the device and make the filtered pair the one the matcher uses
+ *      (what MIMC_main.c:304-350 does with host copies for its 24 filtered passes); output planes start as
+ *      zeros.  kernel = NULL goes back to the pair as handed over.  Nothing crosses PCIe.
+ *      mimc3_ctx_get_images downloads the pair currently in use (either pointer may be NULL). --------- */
+int mimc3_ctx_filter_images(mimc3_ctx *ctx, const float *kernel, int32_t kh, int32_t kw);
+int mimc3_ctx_get_images(mimc3_ctx *ctx, float *i0, float *i1);
+
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */
 int mimc3_ctx_enable_timing(mimc3_ctx *ctx, int32_t on);

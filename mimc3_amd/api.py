@@ -62,6 +62,10 @@ _lib.mimc3_dpf1_workspace_bytes.argtypes = [C.c_int32]
 _lib.mimc3_dpf1_workspace_bytes.restype = C.c_int64
 _lib.mimc3_get_dpf1_dev.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp,
                                     C.c_float, C.c_float, _vp, C.POINTER(C.c_int32), _vp]
+_lib.mimc3_float_conv2.argtypes = [_vp, _f32p, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _f32p]
+_lib.mimc3_float_conv2_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _vp, _vp, _vp]
+_lib.mimc3_ctx_filter_images.argtypes = [_vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_ctx_get_images.argtypes = [_vp, _vp, _vp]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
@@ -203,6 +207,35 @@ class Context:
                                     max_sweeps, d_work, d_sweeps=None, stream=0):
         _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
                                               d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- N2: image pre-filter ---------------------------------------------------------------------
+    def GMA_float_conv2(self, img, kernel, out=None):
+        """GMA_float_conv2 (MIMC_module.c:2517-2585). `out` is in/out as in the reference (its border takes part in
+        the minimum); default = a zero plane, which is what a fresh GMA_float_create gives the CLI."""
+        img = np.ascontiguousarray(img, np.float32)
+        kernel = np.ascontiguousarray(kernel, np.float32)
+        o = np.zeros_like(img) if out is None else np.array(out, np.float32, order="C")
+        _check(_lib.mimc3_float_conv2(self._h, img, img.shape[0], img.shape[1], kernel, kernel.shape[0], kernel.shape[1], o),
+               "GMA_float_conv2")
+        return o
+
+    def GMA_float_conv2_dev(self, d_in, H, W, kernel, d_out, d_scratch, stream=0):
+        kernel = np.ascontiguousarray(kernel, np.float32)
+        _check(_lib.mimc3_float_conv2_dev(self._h, d_in, H, W, kernel, kernel.shape[0], kernel.shape[1], d_out, d_scratch, stream),
+               "GMA_float_conv2_dev")
+
+    def filter_images(self, kernel):
+        """Filter the resident pair on the device and match on the filtered pair from now on; None = back to raw."""
+        if kernel is None:
+            _check(_lib.mimc3_ctx_filter_images(self._h, None, 0, 0), "filter_images")
+            return
+        k = np.ascontiguousarray(kernel, np.float32)
+        _check(_lib.mimc3_ctx_filter_images(self._h, k.ctypes.data_as(_vp), k.shape[0], k.shape[1]), "filter_images")
+
+    def get_images(self, H, W):
+        i0 = np.empty((H, W), np.float32); i1 = np.empty((H, W), np.float32)
+        _check(_lib.mimc3_ctx_get_images(self._h, i0.ctypes.data_as(_vp), i1.ctypes.data_as(_vp)), "get_images")
+        return i0, i1
 
     # -- N1: clustering, dpf0, dpf1 -------------------------------------------------------------
     def calc_mean_var_num_dp_cluster(self, dp, kmax=None):

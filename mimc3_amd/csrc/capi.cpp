@@ -13,6 +13,7 @@
 #include "match_kernel.h"
 #include "qm_kernel.h"
 #include "n1_kernel.h"
+#include "conv2_kernel.h"
 
 namespace mimc3 {
 static thread_local std::string g_err;
@@ -68,6 +69,8 @@ struct mimc3_ctx {
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
     DevBuf qm_io, qm_work;              // QM staging / workspace
     DevBuf n1_io, n1_work;              // clustering / dpf0 / dpf1 staging and workspace
+    const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
+    DevBuf filt0, filt1, conv_io;       // pre-filtered pair (mimc3_ctx_filter_images), conv2 staging
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -114,6 +117,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
+    c->filt0.release(); c->filt1.release(); c->conv_io.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -191,8 +195,8 @@ extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *
     HIP_TRY(hipMemcpyAsync(c->own_i0.p, i0, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->own_i1.p, i1, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->d_i0 = static_cast<const float *>(c->own_i0.p);
-    c->d_i1 = static_cast<const float *>(c->own_i1.p);
+    c->d_i0 = c->raw_i0 = static_cast<const float *>(c->own_i0.p);
+    c->d_i1 = c->raw_i1 = static_cast<const float *>(c->own_i1.p);
     c->H = H; c->W = W;
     return prepare_u8(c);
 }
@@ -200,7 +204,7 @@ extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *
 extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
 {
     if (!c || !d_i0 || !d_i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_dev: bad argument");
-    c->d_i0 = d_i0; c->d_i1 = d_i1; c->H = H; c->W = W;
+    c->d_i0 = c->raw_i0 = d_i0; c->d_i1 = c->raw_i1 = d_i1; c->H = H; c->W = W;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());   // the caller's producer stream is unknown: make the pixels visible
     return prepare_u8(c);
@@ -565,5 +569,90 @@ extern "C" int mimc3_get_dpf1(mimc3_ctx *c, int32_t dimy, int32_t dimx, int32_t 
     HIP_TRY(hipMemcpyAsync(dpf_dx, b + o_dx, 4 * N, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(dpf_dy, b + o_dy, 4 * N, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N2: image pre-filter
+// ---------------------------------------------------------------------------------------------
+static int conv2_args(mimc3::Conv2Args &a, const float *d_in, int32_t H, int32_t W, const float *kernel, int32_t kh, int32_t kw,
+                      float *d_out, uint32_t *d_min)
+{
+    if (!d_in || !d_out || !kernel || !d_min || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || kh * kw > mimc3::kConvMaxTaps ||
+        kh > H || kw > W)
+        return mimc3::fail(MIMC3_EINVAL, "conv2: bad argument (kernel at most 81 taps, no larger than the image)");
+    a.in = d_in; a.out = d_out; a.H = H; a.W = W; a.kh = kh; a.kw = kw; a.minkey = d_min;
+    std::memcpy(a.k, kernel, sizeof(float) * (size_t)kh * kw);
+    return 0;
+}
+
+extern "C" int mimc3_float_conv2_dev(mimc3_ctx *c, const float *d_in, int32_t H, int32_t W, const float *kernel, int32_t kh,
+                                     int32_t kw, float *d_out, void *d_scratch, void *stream)
+{
+    if (!c) return mimc3::fail(MIMC3_EINVAL, "mimc3_float_conv2_dev: ctx is NULL");
+    mimc3::Conv2Args a{};
+    int rc = conv2_args(a, d_in, H, W, kernel, kh, kw, d_out, static_cast<uint32_t *>(d_scratch));
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = mimc3::launch_conv2(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "conv2 kernel launch");
+    return 0;
+}
+
+extern "C" int mimc3_float_conv2(mimc3_ctx *c, const float *in, int32_t H, int32_t W, const float *kernel, int32_t kh, int32_t kw,
+                                 float *out)
+{
+    if (!c || !in || !out || !kernel || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_float_conv2: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * (size_t)H * W;
+    HIP_TRY(c->conv_io.reserve(2 * al256(bytes) + 256));
+    char *b = static_cast<char *>(c->conv_io.p);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b, in, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b + al256(bytes), out, bytes, hipMemcpyHostToDevice, s));     // `out` is in/out: its border is read
+    int rc = mimc3_float_conv2_dev(c, reinterpret_cast<const float *>(b), H, W, kernel, kh, kw, reinterpret_cast<float *>(b + al256(bytes)),
+                                   b + 2 * al256(bytes), s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, b + al256(bytes), bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int mimc3_ctx_filter_images(mimc3_ctx *c, const float *kernel, int32_t kh, int32_t kw)
+{
+    if (!c) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_filter_images: ctx is NULL");
+    if (!c->raw_i0 || !c->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_ctx_filter_images: images not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!kernel) {                                   // back to the pair as handed over
+        c->d_i0 = c->raw_i0; c->d_i1 = c->raw_i1;
+        return prepare_u8(c);
+    }
+    const size_t bytes = sizeof(float) * (size_t)c->H * c->W;
+    HIP_TRY(c->filt0.reserve(bytes));
+    HIP_TRY(c->filt1.reserve(bytes));
+    HIP_TRY(c->conv_io.reserve(256));
+    hipStream_t s = c->stream;
+    // the reference filters into freshly malloc'ed planes whose border it never writes (MIMC_main.c:304-312): zeros (T4)
+    HIP_TRY(hipMemsetAsync(c->filt0.p, 0, bytes, s));
+    HIP_TRY(hipMemsetAsync(c->filt1.p, 0, bytes, s));
+    int rc = mimc3_float_conv2_dev(c, c->raw_i0, c->H, c->W, kernel, kh, kw, static_cast<float *>(c->filt0.p), c->conv_io.p, s);
+    if (rc) return rc;
+    rc = mimc3_float_conv2_dev(c, c->raw_i1, c->H, c->W, kernel, kh, kw, static_cast<float *>(c->filt1.p), c->conv_io.p, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    c->d_i0 = static_cast<const float *>(c->filt0.p);
+    c->d_i1 = static_cast<const float *>(c->filt1.p);
+    return prepare_u8(c);
+}
+
+extern "C" int mimc3_ctx_get_images(mimc3_ctx *c, float *i0, float *i1)
+{
+    if (!c || (!i0 && !i1)) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_get_images: bad argument");
+    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_ctx_get_images: images not set");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * (size_t)c->H * c->W;
+    if (i0) HIP_TRY(hipMemcpyAsync(i0, c->d_i0, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (i1) HIP_TRY(hipMemcpyAsync(i1, c->d_i1, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -624,3 +624,37 @@ int32_t orc_get_dpf1(int32_t dimy, int32_t dimx, int32_t *dpf, float *dx, float 
     free(bx); free(by); free(noi); free(v);
     return NOI;
 }
+
+/* =======================================================================================
+ * N2  image pre-filter                                             MIMC_module.c:2517-2585
+ * GMA_float_conv2: 2-D correlation with a small kernel over the interior, null DN (value+0.5 truncating to 0)
+ * poisoning its whole stencil, then the whole plane shifted so that its minimum becomes 1 and the poisoned
+ * pixels 0.  `out` is IN/OUT: the reference never writes the border rows/columns of `out`, yet its minimum
+ * search (:2555-2565) and the shift of the right-hand border columns (:2568-2582, the loop runs to dimx_in)
+ * read them -- whatever the caller's buffer holds there takes part (fresh large mallocs: zeros, T4).
+ * ======================================================================================= */
+void orc_float_conv2(const float *in, int32_t H, int32_t W, const float *kernel, int32_t kh, int32_t kw, float *out)
+{
+    const int32_t ox = kw / 2, oy = kh / 2;
+    const float nanv = sqrt(-1.0);
+    for (int32_t r = oy; r < H - oy; r++)
+        for (int32_t c = ox; c < W - ox; c++) {
+            float s = 0;
+            for (int32_t a = 0; a < kh; a++)
+                for (int32_t b = 0; b < kw; b++) {
+                    const float v = in[(size_t)(r + a - oy) * W + c + b - ox];
+                    const float dn = (int32_t)(v + 0.5) ? v : nanv;          /* f32 + f64 0.5, truncation */
+                    s += dn * kernel[a * kw + b];
+                }
+            out[(size_t)r * W + c] = s;
+        }
+    float mn = 1e+37;
+    for (size_t i = 0; i < (size_t)H * W; i++)
+        if (out[i] < mn) mn = out[i];
+    for (int32_t r = oy; r < H - oy; r++)
+        for (int32_t c = ox; c < W; c++) {
+            float *o = out + (size_t)r * W + c;
+            if (isnan(*o)) *o = 0;
+            else *o -= mn - 1;
+        }
+}

@@ -77,6 +77,10 @@ class Oracle:
         self._d1.restype = C.c_int32
         self._d1.argtypes = [C.c_int32, C.c_int32, _i32p, _f32p, _f32p, _i32p, C.c_int32, _f32p, C.c_int32, _i32p, _f64p,
                              C.c_float, C.c_float]
+        # N2: pre-filter
+        self._conv = getattr(self.lib, p + "float_conv2")
+        self._conv.restype = None
+        self._conv.argtypes = [_f32p, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _f32p]
         self._nthr = getattr(self.lib, p + "num_threads")
         self._nthr.restype = C.c_int
 
@@ -171,6 +175,15 @@ class Oracle:
         self._d1(dimy, dimx, d.reshape(-1), x.reshape(-1), y.reshape(-1), ruv, ruv.shape[0], mvn, mvn.shape[1],
                  np.ascontiguousarray(nclus, np.int32), np.ascontiguousarray(xyuvav, np.float64), dt, mpp)
         return d, x, y
+
+    # -- N2 ---------------------------------------------------------------------------------
+    def float_conv2(self, img, kernel, out=None):
+        """GMA_float_conv2 (:2517-2585). `out` is in/out (its border takes part); default zeros (T4)."""
+        img = np.ascontiguousarray(img, np.float32)
+        kernel = np.ascontiguousarray(kernel, np.float32)
+        o = np.zeros_like(img) if out is None else np.array(out, np.float32, order="C")
+        self._conv(img, img.shape[0], img.shape[1], kernel, kernel.shape[0], kernel.shape[1], o)
+        return o
 
     # -- reference only: candidates -> QM input (N1 rows, used to make realistic fixtures) ----
     def postprocess_prep(self, dp, xyuvav, dimx, dimy, dt, mpp, meter_per_spacing, radius_dpf1=3.0, kmax=32):

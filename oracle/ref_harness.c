@@ -291,3 +291,11 @@ int ref_get_dpf1(int32_t dimy, int32_t dimx, int32_t *dpf, float *dx, float *dy,
     UNWRAP(gr); UNWRAP(gx); UNWRAP(gy); UNWRAP(gd); UNWRAP(xy);
     return 0;
 }
+
+/* N2: GMA_float_conv2 (:2517-2585); out is in/out (its border is read, see the restatement's header) */
+void ref_float_conv2(const float *in, int32_t H, int32_t W, const float *kernel, int32_t kh, int32_t kw, float *out)
+{
+    GMA_float *gi = wrap_float(in, H, W), *gk = wrap_float(kernel, kh, kw), *go = wrap_float(out, H, W);
+    GMA_float_conv2(gi, gk, go);
+    UNWRAP(gi); UNWRAP(gk); UNWRAP(go);
+}

@@ -109,6 +109,17 @@ def main():
             ruv=ruv, mvn=mvn, nclus=nclus, dpf0=dpf0, dpf1=d1, dx1=x1, dy1=y1)
         print(f"{name}: kmax={kmax} empty={(nclus == 0).sum()} dpf0<0={(dpf0 < 0).sum()} dpf1<0={(d1 < 0).sum()}")
 
+    # N2: the CLI's three pre-filter kernels on an 8-bit image with nulls
+    c = edit_case("nulls_q4", synth.make_small(**MATCH_CASES["nulls_q4"]))
+    ks = {"ddx": np.array([[-1, 0, 1]], np.float32), "ddy": np.array([[-1], [0], [1]], np.float32),
+          "laplacian": np.array([[-1 / 8] * 3, [-1 / 8, 1, -1 / 8], [-1 / 8] * 3], np.float32)}
+    d = {"img": c.i0.astype(np.uint8)}
+    for n, k in ks.items():
+        d["k_" + n] = k
+        d["out_" + n] = ref.float_conv2(c.i0, k)
+    np.savez_compressed(os.path.join(OUT, "conv2_nulls.npz"), **d)
+    print("conv2_nulls:", {n: (float(d["out_" + n].min()), float(d["out_" + n].max())) for n in ks})
+
 
 if __name__ == "__main__":
     main()

@@ -49,3 +49,11 @@ def test_n1_golden(oracle, path):
     assert np.array_equal(d, z["dpf1"])
     assert_bits_equal(x, z["dx1"], "dx"); assert_bits_equal(y, z["dy1"], "dy")
     assert (z["dpf0"] < 0).sum() > (d < 0).sum() > 0
+
+
+@pytest.mark.parametrize("path", golden_files("conv2_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_conv2_golden(oracle, path):
+    z = np.load(path)
+    img = z["img"].astype(np.float32)
+    for name in ("ddx", "ddy", "laplacian"):
+        assert_bits_equal(oracle.float_conv2(img, z["k_" + name]), z["out_" + name], name)

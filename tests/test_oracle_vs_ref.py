@@ -74,3 +74,18 @@ def test_n1_vs_reference(oracle, reference, dims):
     ra = reference.get_dpf1(d0, ruv, a[0], a[1], xy, 16.0, 15.0)
     rb = oracle.get_dpf1(d0, ruv, a[0], a[1], xy, 16.0, 15.0)
     assert np.array_equal(ra[0], rb[0]); assert_bits_equal(ra[1], rb[1], "dx"); assert_bits_equal(ra[2], rb[2], "dy")
+
+
+def test_conv2_vs_reference(oracle, reference):
+    """GMA_float_conv2 (:2517-2585): CLI kernels and odd ones, zero and dirty `out` borders, null DN"""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(70, 93)).astype(np.float32)
+    img[rng.random(img.shape) < 0.05] = 0.0
+    img[5, 5] = 0.4; img[6, 5] = -0.7; img[7, 5] = -1.6
+    ks = [np.array([[-1, 0, 1]], np.float32), np.array([[-1], [0], [1]], np.float32),
+          np.array([[-1 / 8] * 3, [-1 / 8, 1, -1 / 8], [-1 / 8] * 3], np.float32),
+          rng.normal(size=(5, 3)).astype(np.float32), rng.normal(size=(2, 2)).astype(np.float32)]
+    for k in ks:
+        assert_bits_equal(oracle.float_conv2(img, k), reference.float_conv2(img, k), f"k{k.shape}")
+        dirty = rng.uniform(-50, 50, img.shape).astype(np.float32)
+        assert_bits_equal(oracle.float_conv2(img, k, dirty), reference.float_conv2(img, k, dirty), f"k{k.shape} dirty")
