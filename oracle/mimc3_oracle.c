@@ -126,45 +126,28 @@ static float ncc_at(const match_ws *w, int pu, int pv)
                    sqrt((nsample * sxx - sx * sx) * (nsample * syy - sy * sy)));
 }
 
-static void match_point(const float *i0, const float *i1, int32_t H, int32_t W, const double *row,
-                        const int32_t *offset, const int32_t *piv, int32_t npiv, int32_t ocw,
-                        float *out3)
+/* find_ncc_peak (:647-801) on an explicit chip [cw][cw] and search area [Dy2][Dx2] (both row-major (v,u)) */
+static void find_peak(const float *chip, int ocw, const float *win, int Dx2, int Dy2, const int32_t *piv, int32_t npiv,
+                      float *out3)
 {
     const int cw = 2 * ocw + 1;
-    int u0 = (int32_t)row[2], v0 = (int32_t)row[3];     /* T6 truncation (:822-823) */
     match_ws w;
-    w.ocw = ocw; w.cw = cw;
-    w.dx2 = abs(piv[2 * (npiv - 1) + 0]) + ocw + 2;     /* :863-866 */
-    w.dy2 = abs(piv[2 * (npiv - 1) + 1]) + ocw + 2;
-    w.Dx2 = 2 * w.dx2 + 1; w.Dy2 = 2 * w.dy2 + 1;
-    float *chip = (float *)malloc(sizeof(float) * cw * cw);
-    float *win = (float *)calloc((size_t)w.Dx2 * w.Dy2, sizeof(float));   /* T4: zero-filled */
-    float *cmap = (float *)calloc((size_t)w.Dx2 * w.Dy2, sizeof(float));  /* T4: last row/col 0.0 */
-    /* a4 chip: no bounds check in the reference; caller guarantees the margin (:845-855) */
-    for (int r = 0; r < cw; r++)
-        memcpy(chip + r * cw, i0 + (size_t)(v0 - ocw + r) * W + (u0 - ocw), sizeof(float) * cw);
-    /* a5 window around uv0+offset, zero outside the image, last row/col untouched (:869-886) */
-    int uc = u0 + offset[0], vc = v0 + offset[1];
-    for (int r = 0; r < 2 * w.dy2; r++) {
-        int cv = vc - w.dy2 + r;
-        for (int c = 0; c < 2 * w.dx2; c++) {
-            int cu = uc - w.dx2 + c;
-            win[(size_t)r * w.Dx2 + c] = (cu >= 0 && cu < W && cv >= 0 && cv < H) ? i1[(size_t)cv * W + cu] : 0.0f;
-            cmap[(size_t)r * w.Dx2 + c] = -2.0f;            /* :678-681 */
-        }
-    }
+    w.ocw = ocw; w.cw = cw; w.Dx2 = Dx2; w.Dy2 = Dy2; w.dx2 = Dx2 / 2; w.dy2 = Dy2 / 2;
+    float *cmap = (float *)calloc((size_t)Dx2 * Dy2, sizeof(float));      /* T4: last row/col 0.0 */
+    for (int r = 0; r < 2 * w.dy2; r++)
+        for (int c = 0; c < 2 * w.dx2; c++) cmap[(size_t)r * Dx2 + c] = -2.0f;   /* :678-681 */
     w.chip = chip; w.win = win; w.cmap = cmap;
 
     float uvncc0 = 0.0f, uvncc1 = 0.0f, best = -2.0f;
-    /* a6 validity (:605-644): counts include the zero last row/col of the window */
+    /* a6 validity (:605-644): counts run over the whole search area */
     int bad_chip = 0, bad_win = 0;
     for (int i = 0; i < cw * cw; i++) if (chip[i] < ORC_MIN_DN) bad_chip++;
-    for (int i = 0; i < w.Dx2 * w.Dy2; i++) if (win[i] < ORC_MIN_DN) bad_win++;
+    for (int i = 0; i < Dx2 * Dy2; i++) if (win[i] < ORC_MIN_DN) bad_win++;
     const float max_ratio = 0.8;
-    if ((float)bad_chip / (float)(cw * cw) > max_ratio || (float)bad_win / (float)(w.Dx2 * w.Dy2) > max_ratio) {
+    if ((float)bad_chip / (float)(cw * cw) > max_ratio || (float)bad_win / (float)(Dx2 * Dy2) > max_ratio) {
         const float nanv = sqrt(-1.0);
         out3[0] = nanv; out3[1] = nanv; out3[2] = -3.0f;
-        free(chip); free(win); free(cmap);
+        free(cmap);
         return;
     }
     int peak_u = w.dx2, peak_v = w.dy2;
@@ -205,7 +188,34 @@ static void match_point(const float *i0, const float *i1, int32_t H, int32_t W, 
     uvncc0 += (float)(peak_u - w.dx2);
     uvncc1 += (float)(peak_v - w.dy2);
     out3[0] = uvncc0; out3[1] = uvncc1; out3[2] = best;
-    free(chip); free(win); free(cmap);
+    free(cmap);
+}
+
+static void match_point(const float *i0, const float *i1, int32_t H, int32_t W, const double *row,
+                        const int32_t *offset, const int32_t *piv, int32_t npiv, int32_t ocw,
+                        float *out3)
+{
+    const int cw = 2 * ocw + 1;
+    int u0 = (int32_t)row[2], v0 = (int32_t)row[3];     /* T6 truncation (:822-823) */
+    const int dx2 = abs(piv[2 * (npiv - 1) + 0]) + ocw + 2;     /* :863-866 */
+    const int dy2 = abs(piv[2 * (npiv - 1) + 1]) + ocw + 2;
+    const int Dx2 = 2 * dx2 + 1, Dy2 = 2 * dy2 + 1;
+    float *chip = (float *)malloc(sizeof(float) * cw * cw);
+    float *win = (float *)calloc((size_t)Dx2 * Dy2, sizeof(float));   /* T4: zero-filled */
+    /* a4 chip: no bounds check in the reference; caller guarantees the margin (:845-855) */
+    for (int r = 0; r < cw; r++)
+        memcpy(chip + r * cw, i0 + (size_t)(v0 - ocw + r) * W + (u0 - ocw), sizeof(float) * cw);
+    /* a5 window around uv0+offset, zero outside the image, last row/col untouched (:869-886) */
+    int uc = u0 + offset[0], vc = v0 + offset[1];
+    for (int r = 0; r < 2 * dy2; r++) {
+        int cv = vc - dy2 + r;
+        for (int c = 0; c < 2 * dx2; c++) {
+            int cu = uc - dx2 + c;
+            win[(size_t)r * Dx2 + c] = (cu >= 0 && cu < W && cv >= 0 && cv < H) ? i1[(size_t)cv * W + cu] : 0.0f;
+        }
+    }
+    find_peak(chip, ocw, win, Dx2, Dy2, piv, npiv, out3);
+    free(chip); free(win);
 }
 
 /* out[N][3] = (du, dv, ncc).  nthreads<=0: OpenMP default.  Returns 0, or -3 on a point whose
@@ -657,4 +667,155 @@ void orc_float_conv2(const float *in, int32_t H, int32_t W, const float *kernel,
             if (isnan(*o)) *o = 0;
             else *o -= mn - 1;
         }
+}
+
+
+/* =======================================================================================
+ * N4  control-point offset                                          MIMC_module.c:33-492
+ * get_offset_image: slow a-priori grid points whose ocw[2] chip is mostly valid are the candidates; they are
+ * shuffled (GMA_double_randperm_row :494-541, srand(time(NULL)) -> `seed` here) and processed in segments:
+ * per point 16 matches (raw + 3 chip-local filters) x (ocw[1], ocw[2]) x (forward, swapped) with the common
+ * (2*AW_CRE+1)^2 rectangular pivot set on a (2*ocw_chip+1)^2 chip, clustered; clusters holding >= 60 % of the 16
+ * vote with their mean.  offset = rounded mean of the votes.  Returns 1 (ok), -1 (not enough CPs, as the
+ * reference), -3 (a candidate's chip would leave the image: the reference reads out of bounds there).
+ * info[0]=#candidates, [1]=#CP threshold, [2]=#segments run, [3]=#CP found; sduv[2] = the vote sums.
+ * ======================================================================================= */
+int orc_get_offset_image(const float *i0, const float *i1, int32_t H, int32_t W, const double *xyuvav, int32_t N,
+                         const int32_t *vec_ocw, float aw_cre, int32_t num_cp_max, int32_t num_cp_min, float ratio_cp,
+                         float thres_spd_cp, const float *const *kern, const int32_t *kdim, uint32_t seed,
+                         int32_t *offset, uint8_t *flag_cp, int32_t *info, float *sduv_out)
+{
+    const int ocw2 = vec_ocw[2];
+    const int ocw_chip = vec_ocw[2] + aw_cre + 2;                 /* int + float -> float -> int (:51) */
+    const int cs = 2 * ocw_chip + 1, ts = cs + 2;
+    int32_t num_cp;
+    if (N * ratio_cp > num_cp_max) num_cp = num_cp_max; else num_cp = (int32_t)(N * ratio_cp);
+    uint8_t *cand = (uint8_t *)malloc(N);
+    int32_t ncand = 0;
+    for (int32_t g = 0; g < N; g++) {
+        float spd = xyuvav[6 * (size_t)g + 4] * xyuvav[6 * (size_t)g + 4] + xyuvav[6 * (size_t)g + 5] * xyuvav[6 * (size_t)g + 5];
+        cand[g] = spd < thres_spd_cp * thres_spd_cp;
+        ncand += cand[g];
+    }
+    const int32_t thres_numpx = (ocw2 * 2 + 1) * (ocw2 * 2 + 1) / 2;
+    for (int32_t g = 0; g < N; g++) {
+        if (!cand[g]) continue;
+        const int u = (int32_t)xyuvav[6 * (size_t)g + 2], v = (int32_t)xyuvav[6 * (size_t)g + 3];
+        if (u - ocw_chip - 1 < 0 || u + ocw_chip + 1 >= W || v - ocw_chip - 1 < 0 || v + ocw_chip + 1 >= H) { free(cand); return -3; }
+        int32_t bad0 = 0;
+        for (int a = -ocw2; a <= ocw2; a++)
+            for (int b = -ocw2; b <= ocw2; b++)
+                if (i0[(size_t)(a + v) * W + b + u] < 0.00001) bad0++;
+        if (bad0 > thres_numpx) { cand[g] = 0; ncand--; }        /* :106 tests i0's count twice, i1's never */
+    }
+    if (info) { info[0] = ncand; info[1] = num_cp; info[2] = 0; info[3] = 0; }
+    if (ncand < num_cp_min) { free(cand); return -1; }
+    if (num_cp > ncand) num_cp = (int32_t)((float)ncand * 0.75);
+    if (info) info[1] = num_cp;
+
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * ncand), *tmp = (int32_t *)malloc(sizeof(int32_t) * ncand);
+    { int32_t n = 0; for (int32_t g = 0; g < N; g++) if (cand[g]) tmp[n++] = g; }
+    free(cand);
+    srand(seed);                                                  /* :517, row shuffle of :519-538 on the row ids */
+    for (int32_t lim = ncand - 1; lim >= 0; lim--) {
+        const int32_t idx = lim != 0 ? (int32_t)(rand() % lim) : 0;
+        order[lim] = tmp[idx]; tmp[idx] = tmp[0]; tmp[0] = tmp[lim];
+    }
+    free(tmp);
+
+    const int npiv_side = (int)(aw_cre * 2 + 1);
+    const int32_t npiv = (int32_t)((aw_cre * 2 + 1) * (aw_cre * 2 + 1));
+    int32_t *piv = (int32_t *)malloc(sizeof(int32_t) * 2 * npiv);
+    { int32_t k = 0; for (int a = -(int)aw_cre; a <= (int)aw_cre; a++) for (int b = -(int)aw_cre; b <= (int)aw_cre; b++) { piv[2 * k] = a; piv[2 * k + 1] = b; k++; } (void)npiv_side; }
+
+    const int32_t nseg = ncand < num_cp_min ? 1 : ncand / num_cp;
+    float sduv[2] = {0.0f, 0.0f};
+    int32_t ncur = 0, ok = 0, segs = 0;
+    for (int32_t sgm = 0; sgm < nseg; sgm++) {
+        const int32_t beg = (int32_t)(ncand * ((float)sgm / (float)nseg)), end = (int32_t)(ncand * ((float)(sgm + 1) / (float)nseg));
+        const int32_t n = end - beg;
+        segs++;
+        float *dp = (float *)calloc((size_t)16 * n * 3, sizeof(float));
+        float *c0 = (float *)malloc(sizeof(float) * (size_t)n * cs * cs), *c1 = (float *)malloc(sizeof(float) * (size_t)n * cs * cs);
+        for (int kk = -1; kk <= 2; kk++) {
+            if (kk < 0) {
+                for (int32_t t = 0; t < n; t++) {
+                    const int32_t g = order[beg + t];
+                    const int u = (int32_t)xyuvav[6 * (size_t)g + 2], v = (int32_t)xyuvav[6 * (size_t)g + 3];
+                    for (int r = 0; r < cs; r++)
+                        for (int c = 0; c < cs; c++) {
+                            c0[((size_t)t * cs + r) * cs + c] = i0[(size_t)(v - ocw_chip + r) * W + u - ocw_chip + c];
+                            c1[((size_t)t * cs + r) * cs + c] = i1[(size_t)(v - ocw_chip + r) * W + u - ocw_chip + c];
+                        }
+                }
+            } else {
+                float *t0 = (float *)malloc(sizeof(float) * ts * ts), *t1 = (float *)malloc(sizeof(float) * ts * ts);
+                float *o0 = (float *)calloc((size_t)ts * ts, sizeof(float)), *o1 = (float *)calloc((size_t)ts * ts, sizeof(float));  /* T4 */
+                for (int32_t t = 0; t < n; t++) {                /* o0/o1 persist from point to point (:259-262) */
+                    const int32_t g = order[beg + t];
+                    const int u = (int32_t)xyuvav[6 * (size_t)g + 2], v = (int32_t)xyuvav[6 * (size_t)g + 3];
+                    for (int r = 0; r < ts; r++)
+                        for (int c = 0; c < ts; c++) {
+                            t0[r * ts + c] = i0[(size_t)(v - ocw_chip - 1 + r) * W + u - ocw_chip - 1 + c];
+                            t1[r * ts + c] = i1[(size_t)(v - ocw_chip - 1 + r) * W + u - ocw_chip - 1 + c];
+                        }
+                    orc_float_conv2(t0, ts, ts, kern[kk], kdim[2 * kk], kdim[2 * kk + 1], o0);
+                    orc_float_conv2(t1, ts, ts, kern[kk], kdim[2 * kk], kdim[2 * kk + 1], o1);
+                    for (int r = 0; r < cs; r++)
+                        for (int c = 0; c < cs; c++) {
+                            c0[((size_t)t * cs + r) * cs + c] = o0[(r + 1) * ts + c + 1];
+                            c1[((size_t)t * cs + r) * cs + c] = o1[(r + 1) * ts + c + 1];
+                        }
+                }
+                free(t0); free(t1); free(o0); free(o1);
+            }
+            for (int c3 = 1; c3 < 3; c3++) {
+                const int ocw = vec_ocw[c3], cw = 2 * ocw + 1;
+                const int32_t slot = (c3 - 1) * 8 + (kk + 1) * 2;
+#pragma omp parallel
+                {
+                    float *ref = (float *)malloc(sizeof(float) * cw * cw);
+                    float r3[3];
+#pragma omp for schedule(dynamic)
+                    for (int32_t t = 0; t < n; t++) {
+                        const float *a0 = c0 + (size_t)t * cs * cs, *a1 = c1 + (size_t)t * cs * cs;
+                        for (int r = 0; r < cw; r++)
+                            memcpy(ref + r * cw, a0 + (size_t)(ocw_chip - ocw + r) * cs + ocw_chip - ocw, sizeof(float) * cw);
+                        find_peak(ref, ocw, a1, cs, cs, piv, npiv, r3);
+                        float *d = dp + ((size_t)slot * n + t) * 3;
+                        d[0] = r3[0]; d[1] = r3[1]; d[2] = r3[2];
+                        for (int r = 0; r < cw; r++)
+                            memcpy(ref + r * cw, a1 + (size_t)(ocw_chip - ocw + r) * cs + ocw_chip - ocw, sizeof(float) * cw);
+                        find_peak(ref, ocw, a0, cs, cs, piv, npiv, r3);
+                        d = dp + ((size_t)(slot + 1) * n + t) * 3;
+                        d[0] = -r3[0]; d[1] = -r3[1]; d[2] = r3[2];
+                    }
+                    free(ref);
+                }
+            }
+        }
+        free(c0); free(c1);
+        float *mvn = (float *)malloc(sizeof(float) * 5 * (size_t)n * 16);
+        int32_t *ncl = (int32_t *)malloc(sizeof(int32_t) * n);
+        orc_cluster_candidates(dp, 16, n, 16, mvn, ncl);
+        for (int32_t t = 0; t < n; t++)
+            for (int32_t c = 0; c < ncl[t]; c++)
+                if (mvn[((size_t)t * 16 + c) * 5 + 4] >= 0.6) {
+                    sduv[0] += mvn[((size_t)t * 16 + c) * 5];
+                    sduv[1] += mvn[((size_t)t * 16 + c) * 5 + 1];
+                    flag_cp[order[beg + t]] = 1;
+                    ncur++;
+                }
+        free(mvn); free(ncl); free(dp);
+        if (num_cp <= ncur) { ok = 1; break; }
+    }
+    free(order); free(piv);
+    if (info) { info[2] = segs; info[3] = ncur; }
+    if (sduv_out) { sduv_out[0] = sduv[0]; sduv_out[1] = sduv[1]; }
+    if (ncur < num_cp && ncur >= num_cp_min) ok = 1;
+    if (!ok) return -1;
+    const float du = sduv[0] / (float)ncur, dv = sduv[1] / (float)ncur;
+    offset[0] = du > 0 ? (int32_t)(du + 0.5) : (int32_t)(du - 0.5);
+    offset[1] = dv > 0 ? (int32_t)(dv + 0.5) : (int32_t)(dv - 0.5);
+    return 1;
 }

@@ -81,6 +81,12 @@ class Oracle:
         self._conv = getattr(self.lib, p + "float_conv2")
         self._conv.restype = None
         self._conv.argtypes = [_f32p, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _f32p]
+        # N4: control-point offset
+        self._cp = getattr(self.lib, p + "get_offset_image")
+        self._cp.restype = C.c_int
+        base = [_f32p, _f32p, C.c_int32, C.c_int32, _f64p, C.c_int32, _i32p, C.c_float, C.c_int32, C.c_int32, C.c_float,
+                C.c_float, C.POINTER(C.c_void_p), _i32p, C.c_uint32, _i32p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+        self._cp.argtypes = base + ([_i32p, _f32p] if kind == "port" else [])
         self._nthr = getattr(self.lib, p + "num_threads")
         self._nthr.restype = C.c_int
 
@@ -184,6 +190,27 @@ class Oracle:
         o = np.zeros_like(img) if out is None else np.array(out, np.float32, order="C")
         self._conv(img, img.shape[0], img.shape[1], kernel, kernel.shape[0], kernel.shape[1], o)
         return o
+
+    # -- N4 ---------------------------------------------------------------------------------
+    def get_offset_image(self, i0, i1, xyuvav, kernels, seed, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500,
+                         num_cp_min=50, ratio_cp=0.03, thres_spd_cp=10.0):
+        """get_offset_image (:33-492) with the shuffle seed pinned. Returns (rc, offset[2], flag_cp[N], info, sduv);
+        info/sduv are None for the reference."""
+        i0 = np.ascontiguousarray(i0, np.float32); i1 = np.ascontiguousarray(i1, np.float32)
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        ks = [np.ascontiguousarray(k, np.float32) for k in kernels]
+        kptr = (C.c_void_p * 3)(*[k.ctypes.data for k in ks])
+        kdim = np.array([d for k in ks for d in k.shape], np.int32)
+        off = np.zeros(2, np.int32)
+        flag = np.zeros(xy.shape[0], np.uint8)
+        args = [i0, i1, i0.shape[0], i0.shape[1], xy, xy.shape[0], np.array(vec_ocw, np.int32), aw_cre, num_cp_max, num_cp_min,
+                ratio_cp, thres_spd_cp, kptr, kdim, seed, off, flag]
+        if self.kind == "port":
+            info = np.zeros(4, np.int32); sduv = np.zeros(2, np.float32)
+            rc = self._cp(*args, info, sduv)
+            return rc, off, flag, info, sduv
+        rc = self._cp(*args)
+        return rc, off, flag, None, None
 
     # -- reference only: candidates -> QM input (N1 rows, used to make realistic fixtures) ----
     def postprocess_prep(self, dp, xyuvav, dimx, dimy, dt, mpp, meter_per_spacing, radius_dpf1=3.0, kmax=32):

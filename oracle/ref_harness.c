@@ -299,3 +299,46 @@ void ref_float_conv2(const float *in, int32_t H, int32_t W, const float *kernel,
     GMA_float_conv2(gi, gk, go);
     UNWRAP(gi); UNWRAP(gk); UNWRAP(go);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * N4: get_offset_image (:33-492).  Its row shuffle seeds rand() with time(NULL) (:517); the library is
+ * linked with -Wl,--wrap=time so that the harness can pin that seed (g_fake_time >= 0) for a repeatable run.
+ * ---------------------------------------------------------------------------------------- */
+#include <time.h>
+static long g_fake_time = -1;
+time_t __real_time(time_t *t);
+time_t __wrap_time(time_t *t)
+{
+    if (g_fake_time < 0) return __real_time(t);
+    if (t) *t = (time_t)g_fake_time;
+    return (time_t)g_fake_time;
+}
+
+int ref_get_offset_image(const float *i0, const float *i1, int32_t H, int32_t W, const double *xyuvav, int32_t N,
+                         const int32_t *vec_ocw, float aw_cre, int32_t num_cp_max, int32_t num_cp_min, float ratio_cp,
+                         float thres_spd_cp, const float *const *kern, const int32_t *kdim, uint32_t seed,
+                         int32_t *offset, uint8_t *flag_cp)
+{
+    for (int k = 0; k < 4; k++) param_mimc2.vec_ocw[k] = vec_ocw[k];
+    param_mimc2.AW_CRE = aw_cre; param_mimc2.num_cp_max = num_cp_max; param_mimc2.num_cp_min = num_cp_min;
+    param_mimc2.ratio_cp = ratio_cp; param_mimc2.thres_spd_cp = thres_spd_cp;
+    GMA_float *ks[3];
+    for (int k = 0; k < 3; k++) ks[k] = wrap_float(kern[k], kdim[2 * k], kdim[2 * k + 1]);
+    kernel = ks;
+    GMA_float *g0 = wrap_float(i0, H, W), *g1 = wrap_float(i1, H, W);
+    GMA_double *xy = wrap_double(xyuvav, N, 6);
+    GMA_uint8 *fl = (GMA_uint8 *)calloc(1, sizeof(GMA_uint8));
+    fl->nrows = N; fl->ncols = 1; fl->data = flag_cp;
+    fl->val = (uint8_t **)calloc((size_t)N, sizeof(uint8_t *));
+    for (int32_t r = 0; r < N; r++) fl->val[r] = flag_cp + r;
+    g_fake_time = (long)seed;
+    int sv; quiet_begin(&sv);
+    int rc = get_offset_image(g0, g1, ks, xy, offset, fl);
+    quiet_end(sv);
+    g_fake_time = -1;
+    free(fl->val); free(fl);
+    UNWRAP(xy); UNWRAP(g0); UNWRAP(g1);
+    for (int k = 0; k < 3; k++) UNWRAP(ks[k]);
+    kernel = NULL;
+    return rc;
+}
