@@ -162,6 +162,28 @@ int mimc3_float_conv2_dev(mimc3_ctx *ctx, const float *d_in, int32_t H, int32_t 
 int mimc3_ctx_filter_images(mimc3_ctx *ctx, const float *kernel, int32_t kh, int32_t kw);
 int mimc3_ctx_get_images(mimc3_ctx *ctx, float *i0, float *i1);
 
+/* ---- N4: control-point offset.  Replaces get_offset_image (MIMC_module.h:34, MIMC_module.c:33-492) incl.
+ *      GMA_double_randperm_row (:494-541).  Works on the context's resident pair AS HANDED OVER (any
+ *      mimc3_ctx_filter_images state is ignored).  The reference's globals travel in mimc3_cp_params; its
+ *      srand(time(NULL)) becomes `seed` (< 0 = time(NULL)), so a run can be repeated.  *status receives the
+ *      reference's return value: 1 = offset valid, -1 = not enough control points (offset untouched; the CLI
+ *      then gives up on the pair, MIMC_main.c:246-252).  flag_cp [N] bytes: set to 1 for every grid point that
+ *      voted (never cleared: pass zeros, as GMA_uint8_create gives).  info (may be NULL) = #candidates, CP
+ *      threshold, segments run, CPs found; sduv (may be NULL) = the two vote sums.
+ *      MIMC3_EBOUNDS if a candidate's chip (+-(vec_ocw[2]+AW_CRE+3) px) leaves the image. ---------------- */
+typedef struct mimc3_cp_params {
+    int32_t vec_ocw[4];       /* param.vec_ocw: [1] and [2] are matched, [2] sizes the chips and the validity test */
+    float aw_cre;             /* param.AW_CRE: rectangular pivot set -AW_CRE..AW_CRE in u and v                  */
+    int32_t num_cp_max, num_cp_min;
+    float ratio_cp, thres_spd_cp;
+    const float *kernel[3];   /* the CLI's three pre-filter kernels (MIMC_main.c:176-194), row-major              */
+    int32_t kdim[3][2];       /* rows, cols of each (at most 3 x 3)                                               */
+    int64_t seed;
+} mimc3_cp_params;
+int mimc3_get_offset_image(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_cp_params *params,
+                           int32_t offset[2], uint8_t *flag_cp, int32_t *status, int32_t *info /*[4]*/,
+                           float *sduv /*[2]*/);
+
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */
 int mimc3_ctx_enable_timing(mimc3_ctx *ctx, int32_t on);

@@ -66,6 +66,17 @@ _lib.mimc3_float_conv2.argtypes = [_vp, _f32p, C.c_int32, C.c_int32, _f32p, C.c_
 _lib.mimc3_float_conv2_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _vp, _vp, _vp]
 _lib.mimc3_ctx_filter_images.argtypes = [_vp, _vp, C.c_int32, C.c_int32]
 _lib.mimc3_ctx_get_images.argtypes = [_vp, _vp, _vp]
+
+
+class CpParams(C.Structure):
+    """mimc3_cp_params (include/mimc3_hip.h): the reference's globals that get_offset_image reads."""
+    _fields_ = [("vec_ocw", C.c_int32 * 4), ("aw_cre", C.c_float), ("num_cp_max", C.c_int32), ("num_cp_min", C.c_int32),
+                ("ratio_cp", C.c_float), ("thres_spd_cp", C.c_float), ("kernel", C.c_void_p * 3), ("kdim", (C.c_int32 * 2) * 3),
+                ("seed", C.c_int64)]
+
+
+_lib.mimc3_get_offset_image.argtypes = [_vp, _f64p, C.c_int32, C.POINTER(CpParams), _i32p,
+                                        np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(C.c_int32), _i32p, _f32p]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
@@ -207,6 +218,29 @@ class Context:
                                     max_sweeps, d_work, d_sweeps=None, stream=0):
         _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
                                               d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- N4: control-point offset -----------------------------------------------------------------
+    def get_offset_image(self, xyuvav, kernels, seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500, num_cp_min=50,
+                         ratio_cp=0.03, thres_spd_cp=10.0):
+        """get_offset_image (MIMC_module.c:33-492) on the resident pair. Defaults = MIMC_main.c:134-170.
+        Returns (status, offset[2], flag_cp[N], info[4], sduv[2]); status 1 = ok, -1 = not enough control points."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        ks = [np.ascontiguousarray(k, np.float32) for k in kernels]
+        p = CpParams()
+        p.vec_ocw[:] = list(vec_ocw)
+        p.aw_cre = aw_cre; p.num_cp_max = num_cp_max; p.num_cp_min = num_cp_min
+        p.ratio_cp = ratio_cp; p.thres_spd_cp = thres_spd_cp; p.seed = seed
+        for i, k in enumerate(ks):
+            p.kernel[i] = k.ctypes.data
+            p.kdim[i][0], p.kdim[i][1] = k.shape
+        off = np.zeros(2, np.int32)
+        flag = np.zeros(xy.shape[0], np.uint8)
+        info = np.zeros(4, np.int32)
+        sduv = np.zeros(2, np.float32)
+        st = C.c_int32(0)
+        _check(_lib.mimc3_get_offset_image(self._h, xy, xy.shape[0], C.byref(p), off, flag, C.byref(st), info, sduv),
+               "get_offset_image")
+        return st.value, off, flag, info, sduv
 
     # -- N2: image pre-filter ---------------------------------------------------------------------
     def GMA_float_conv2(self, img, kernel, out=None):

@@ -14,6 +14,9 @@
 #include "qm_kernel.h"
 #include "n1_kernel.h"
 #include "conv2_kernel.h"
+#include "cp_kernel.h"
+#include <ctime>
+#include <cstdlib>
 
 namespace mimc3 {
 static thread_local std::string g_err;
@@ -71,6 +74,7 @@ struct mimc3_ctx {
     DevBuf n1_io, n1_work;              // clustering / dpf0 / dpf1 staging and workspace
     const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
     DevBuf filt0, filt1, conv_io;       // pre-filtered pair (mimc3_ctx_filter_images), conv2 staging
+    DevBuf cp_buf;                      // control-point stage: one arena carved per call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -117,7 +121,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
-    c->filt0.release(); c->filt1.release(); c->conv_io.release();
+    c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -654,5 +658,223 @@ extern "C" int mimc3_ctx_get_images(mimc3_ctx *c, float *i0, float *i1)
     if (i0) HIP_TRY(hipMemcpyAsync(i0, c->d_i0, bytes, hipMemcpyDeviceToHost, c->stream));
     if (i1) HIP_TRY(hipMemcpyAsync(i1, c->d_i1, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N4: control-point offset (get_offset_image, MIMC_module.c:33-492)
+// Host side: candidate bookkeeping, the reference's row shuffle, segment loop, the sequential border recurrence
+// of the reused filter plane, vote accumulation (f32, candidate order).  Device side: everything that touches
+// pixels (validity counts, chips, chip-local filters, 16 matches per candidate, clustering).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Arena {
+    char *base; size_t used = 0, cap;
+    Arena(void *p, size_t c) : base(static_cast<char *>(p)), cap(c) {}
+    template <class T> T *take(size_t n) { T *r = reinterpret_cast<T *>(base + used); used += al256(sizeof(T) * n); return r; }
+};
+}  // namespace
+
+extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_t N, const mimc3_cp_params *p, int32_t offset[2],
+                                      uint8_t *flag_cp, int32_t *status, int32_t *info, float *sduv_out)
+{
+    if (!c || !xyuvav || !p || !offset || !flag_cp || !status || N <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: bad argument");
+    if (!c->raw_i0 || !c->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: images not set");
+    for (int k = 0; k < 3; k++)
+        if (!p->kernel[k] || p->kdim[k][0] < 1 || p->kdim[k][0] > 3 || p->kdim[k][1] < 1 || p->kdim[k][1] > 3)
+            return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: three pre-filter kernels of at most 3x3 are required");
+    const int ocw2 = p->vec_ocw[2];
+    const int ocw_chip = (int32_t)(p->vec_ocw[2] + p->aw_cre + 2);                 // :51
+    const int cs = 2 * ocw_chip + 1, ts = cs + 2;
+    const int awc = (int)p->aw_cre;
+    if (ocw2 < 1 || p->vec_ocw[1] < 1 || p->vec_ocw[1] > ocw2 || awc < 0 || ocw_chip - ocw2 - 2 < 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: need 1 <= vec_ocw[1] <= vec_ocw[2] and AW_CRE >= 0");
+    *status = -1;
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    if (sduv_out) sduv_out[0] = sduv_out[1] = 0.0f;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int H = c->H, W = c->W;
+
+    // ---- candidates: slow a-priori points (:64-78) whose ocw[2] chip of i0 is mostly valid (:81-112)
+    int32_t num_cp;
+    if (N * p->ratio_cp > p->num_cp_max) num_cp = p->num_cp_max; else num_cp = (int32_t)(N * p->ratio_cp);
+    std::vector<int32_t> rows;
+    for (int32_t g = 0; g < N; g++) {
+        const float spd = xyuvav[6 * (size_t)g + 4] * xyuvav[6 * (size_t)g + 4] + xyuvav[6 * (size_t)g + 5] * xyuvav[6 * (size_t)g + 5];
+        if (spd < p->thres_spd_cp * p->thres_spd_cp) rows.push_back(g);
+    }
+    std::vector<int32_t> uv(2 * rows.size());
+    for (size_t i = 0; i < rows.size(); i++) {
+        const int u = (int32_t)xyuvav[6 * (size_t)rows[i] + 2], v = (int32_t)xyuvav[6 * (size_t)rows[i] + 3];
+        if (u - ocw_chip - 1 < 0 || u + ocw_chip + 1 >= W || v - ocw_chip - 1 < 0 || v + ocw_chip + 1 >= H)
+            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_get_offset_image: grid point " + std::to_string(rows[i]) +
+                                                  " control-point chip leaves the image (the reference reads out of bounds there)");
+        uv[2 * i] = u; uv[2 * i + 1] = v;
+    }
+    if (!rows.empty()) {
+        const size_t n0 = rows.size();
+        HIP_TRY(c->cp_buf.reserve(al256(8 * n0) + al256(4 * n0)));
+        Arena a0(c->cp_buf.p, c->cp_buf.cap);
+        int32_t *d_uv = a0.take<int32_t>(2 * n0), *d_cnt = a0.take<int32_t>(n0);
+        HIP_TRY(hipMemcpyAsync(d_uv, uv.data(), 8 * n0, hipMemcpyHostToDevice, s));
+        HIP_TRY(mimc3::launch_cp_count_invalid(c->raw_i0, H, W, d_uv, (int32_t)n0, ocw2, d_cnt, s));
+        std::vector<int32_t> cnt(n0);
+        HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, 4 * n0, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const int32_t thres_numpx = (ocw2 * 2 + 1) * (ocw2 * 2 + 1) / 2;
+        size_t w = 0;
+        for (size_t i = 0; i < n0; i++)
+            if (!(cnt[i] > thres_numpx)) { rows[w] = rows[i]; uv[2 * w] = uv[2 * i]; uv[2 * w + 1] = uv[2 * i + 1]; w++; }   // :106 (i0's count only)
+        rows.resize(w); uv.resize(2 * w);
+    }
+    const int32_t ncand = (int32_t)rows.size();
+    if (info) { info[0] = ncand; info[1] = num_cp; }
+    if (ncand < p->num_cp_min) return 0;                                           // :119-123 (status -1)
+    if (num_cp > ncand) num_cp = (int32_t)((float)ncand * 0.75);                   // :125-129
+    if (info) info[1] = num_cp;
+
+    // ---- GMA_double_randperm_row (:494-541) on the candidate ids
+    std::vector<int32_t> order(ncand), tmp(ncand);
+    for (int32_t i = 0; i < ncand; i++) tmp[i] = i;
+    srand(p->seed < 0 ? (unsigned)time(nullptr) : (unsigned)p->seed);
+    for (int32_t lim = ncand - 1; lim >= 0; lim--) {
+        const int32_t idx = lim != 0 ? (int32_t)(rand() % lim) : 0;
+        order[lim] = tmp[idx]; tmp[idx] = tmp[0]; tmp[0] = tmp[lim];
+    }
+
+    const int32_t nseg = ncand < p->num_cp_min ? 1 : ncand / num_cp;                // :171
+    std::vector<int32_t> seg(nseg + 1);
+    seg[0] = 0;
+    int32_t nmax = 0;
+    for (int32_t k = 1; k <= nseg; k++) {
+        seg[k] = (int32_t)(ncand * ((float)k / (float)nseg));                      // :179
+        nmax = std::max(nmax, seg[k] - seg[k - 1]);
+    }
+
+    // ---- common rectangular pivot set (:150-162), replicated per point for the CSR interface
+    const int32_t npiv = (int32_t)((p->aw_cre * 2 + 1) * (p->aw_cre * 2 + 1));
+    std::vector<int32_t> piv;
+    for (int a = -awc; a <= awc; a++) for (int b = -awc; b <= awc; b++) { piv.push_back(a); piv.push_back(b); }
+    if ((int32_t)piv.size() != 2 * npiv) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: AW_CRE must be integral");
+    std::vector<int32_t> piv_all((size_t)2 * npiv * nmax);
+    std::vector<int64_t> piv_off((size_t)nmax + 1);
+    std::vector<double> xy_atlas((size_t)6 * nmax, 0.0);
+    for (int32_t t = 0; t < nmax; t++) {
+        std::memcpy(&piv_all[(size_t)2 * npiv * t], piv.data(), sizeof(int32_t) * 2 * npiv);
+        piv_off[t] = (int64_t)npiv * t;
+        xy_atlas[6 * (size_t)t + 2] = ocw_chip; xy_atlas[6 * (size_t)t + 3] = (double)t * cs + ocw_chip;
+    }
+    piv_off[nmax] = (int64_t)npiv * nmax;
+
+    const size_t nm = (size_t)nmax;
+    const size_t need = al256(8 * nm) + al256(48 * nm) + al256(8 * npiv * nm) + al256(8 * (nm + 1)) + 2 * al256(4 * nm * cs * cs) +
+                        2 * al256(4 * nm * ts * ts) + 4 * al256(4 * nm) + al256(4 * 48 * nm) + al256(4 * 80 * nm) + al256(4 * nm) + 256;
+    HIP_TRY(c->cp_buf.reserve(need));
+    Arena ar(c->cp_buf.p, c->cp_buf.cap);
+    int32_t *d_uv = ar.take<int32_t>(2 * nm);
+    double *d_xy = ar.take<double>(6 * nm);
+    int32_t *d_piv = ar.take<int32_t>((size_t)2 * npiv * nm);
+    int64_t *d_poff = ar.take<int64_t>(nm + 1);
+    float *d_a0 = ar.take<float>(nm * cs * cs), *d_a1 = ar.take<float>(nm * cs * cs);
+    float *d_t0 = ar.take<float>(nm * ts * ts), *d_t1 = ar.take<float>(nm * ts * ts);
+    float *d_imin0 = ar.take<float>(nm), *d_imin1 = ar.take<float>(nm), *d_mn0 = ar.take<float>(nm), *d_mn1 = ar.take<float>(nm);
+    float *d_dp = ar.take<float>(48 * nm);
+    float *d_mvn = ar.take<float>(80 * nm);
+    int32_t *d_ncl = ar.take<int32_t>(nm);
+    int32_t *d_kmax = ar.take<int32_t>(1);
+    HIP_TRY(hipMemcpyAsync(d_xy, xy_atlas.data(), 48 * nm, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_piv, piv_all.data(), sizeof(int32_t) * piv_all.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_poff, piv_off.data(), 8 * (nm + 1), hipMemcpyHostToDevice, s));
+
+    float sduv[2] = {0.0f, 0.0f};
+    int32_t ncur = 0, segs = 0;
+    bool ok = false;
+    std::vector<int32_t> uv_seg;
+    std::vector<float> imin0(nmax), imin1(nmax), mn0(nmax), mn1(nmax), mvn((size_t)80 * nmax);
+    std::vector<int32_t> ncl(nmax);
+    for (int32_t sg = 0; sg < nseg; sg++) {
+        const int32_t beg = seg[sg], n = seg[sg + 1] - seg[sg];
+        segs++;
+        if (n <= 0) continue;
+        uv_seg.resize(2 * (size_t)n);
+        for (int32_t t = 0; t < n; t++) { uv_seg[2 * t] = uv[2 * order[beg + t]]; uv_seg[2 * t + 1] = uv[2 * order[beg + t] + 1]; }
+        HIP_TRY(hipMemcpyAsync(d_uv, uv_seg.data(), 8 * (size_t)n, hipMemcpyHostToDevice, s));
+        for (int kk = -1; kk <= 2; kk++) {
+            if (kk < 0) {
+                HIP_TRY(mimc3::launch_cp_extract(c->raw_i0, H, W, d_uv, n, ocw_chip, d_a0, s));
+                HIP_TRY(mimc3::launch_cp_extract(c->raw_i1, H, W, d_uv, n, ocw_chip, d_a1, s));
+            } else {
+                const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
+                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t0, d_imin0, s));
+                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t1, d_imin1, s));
+                HIP_TRY(hipMemcpyAsync(imin0.data(), d_imin0, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(imin1.data(), d_imin1, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                // the reference's output plane is reused from point to point (:259-262): its never-written border cells
+                // stay 0 (T4), its right-hand border columns accumulate the shifts (:2568-2582); both enter the minimum
+                const int ox = kw / 2, oy = kh / 2;
+                const bool has_zero = ox > 0 || oy > 0;
+                for (int im = 0; im < 2; im++) {
+                    const float *imn = im ? imin1.data() : imin0.data();
+                    float *mn = im ? mn1.data() : mn0.data();
+                    float b = 0.0f;
+                    for (int32_t t = 0; t < n; t++) {
+                        float m = 1e+37f;
+                        if (imn[t] < m) m = imn[t];
+                        if (has_zero && 0.0f < m) m = 0.0f;
+                        if (ox > 0 && b < m) m = b;
+                        mn[t] = m;
+                        if (ox > 0) b = (b != b) ? 0.0f : b - (m - 1.0f);
+                    }
+                }
+                HIP_TRY(hipMemcpyAsync(d_mn0, mn0.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(d_mn1, mn1.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+                HIP_TRY(mimc3::launch_cp_shift_copy(d_t0, d_mn0, n, ocw_chip, d_a0, s));
+                HIP_TRY(mimc3::launch_cp_shift_copy(d_t1, d_mn1, n, ocw_chip, d_a1, s));
+            }
+            for (int c3 = 1; c3 < 3; c3++) {                                       // :330-384
+                const int ocw = p->vec_ocw[c3];
+                const int32_t slot = (c3 - 1) * 8 + (kk + 1) * 2;
+                for (int sw = 0; sw < 2; sw++) {
+                    mimc3::MatchArgs a{};
+                    a.i0 = d_a0; a.i1 = d_a1; a.H = n * cs; a.W = cs;
+                    a.xyuvav = d_xy; a.N = n; a.off_u = 0; a.off_v = 0;
+                    a.piv_uv = d_piv; a.piv_off = d_poff; a.ocw = ocw; a.swap = sw; a.win_half = ocw_chip;
+                    a.thr = min_dn_threshold();
+                    a.out = d_dp + (size_t)(slot + sw) * n * 3;
+                    const int reach = ocw_chip - ocw - 2;
+                    hipError_t e = mimc3::launch_match_f32(a, reach, reach, npiv, s);
+                    if (e != hipSuccess) return mimc3::hip_fail(e, "control-point match launch");
+                    if (sw) HIP_TRY(mimc3::launch_negate_uv(a.out, n, s));          // :376-377
+                }
+            }
+        }
+        // ---- clusters of the 16 matches; those holding >= 60 % vote with their mean (:392-413)
+        mimc3::ClusterArgs ca{};
+        ca.dp = d_dp; ca.ndp = 16; ca.N = n; ca.Kmax = 16; ca.mvn = d_mvn; ca.nclus = d_ncl; ca.kmax_seen = d_kmax;
+        HIP_TRY(mimc3::launch_cluster(ca, s));
+        HIP_TRY(hipMemcpyAsync(mvn.data(), d_mvn, 4 * 80 * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ncl.data(), d_ncl, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int32_t t = 0; t < n; t++)
+            for (int32_t k = 0; k < ncl[t]; k++)
+                if (mvn[((size_t)t * 16 + k) * 5 + 4] >= 0.6) {
+                    sduv[0] += mvn[((size_t)t * 16 + k) * 5];
+                    sduv[1] += mvn[((size_t)t * 16 + k) * 5 + 1];
+                    flag_cp[rows[order[beg + t]]] = 1;
+                    ncur++;
+                }
+        if (num_cp <= ncur) { ok = true; break; }                                  // :424-430
+    }
+    if (info) { info[2] = segs; info[3] = ncur; }
+    if (sduv_out) { sduv_out[0] = sduv[0]; sduv_out[1] = sduv[1]; }
+    if (ncur < num_cp && ncur >= p->num_cp_min) ok = true;                          // :451-455
+    if (!ok) return 0;                                                              // status -1 (:478-484)
+    const float du = sduv[0] / (float)ncur, dv = sduv[1] / (float)ncur;             // :460-476
+    offset[0] = du > 0 ? (int32_t)(du + 0.5) : (int32_t)(du - 0.5);
+    offset[1] = dv > 0 ? (int32_t)(dv + 0.5) : (int32_t)(dv - 0.5);
+    *status = 1;
     return 0;
 }

@@ -1,0 +1,153 @@
+// cp_kernel.hip -- device pieces of get_offset_image (MIMC_module.c:33-492) for gfx950: chip validity counts,
+// the per-point image chips ("atlas": tile t = chip of control-point candidate t, stacked vertically so that the
+// matcher kernel can treat the stack as one tall image), and the chip-local pre-filter.  The matching itself is the
+// general matcher kernel run on the atlas with the full-square search area (MatchArgs::win_half).
+//
+// The reference filters every chip with GMA_float_conv2 into ONE output plane that it reuses from point to point
+// (:259-262, :292-293); what survives in that plane's border takes part in the next chip's minimum.  The stencil and
+// the per-chip interior minimum are computed here for all chips at once; the tiny sequential recurrence over the
+// chips (border state -> minimum -> shift) runs on the host between the two launches (capi.cpp).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cp_kernel.h"
+
+namespace mimc3 {
+namespace {
+
+__global__ __launch_bounds__(256) void cp_count_invalid(const float *__restrict__ img, int32_t H, int32_t W,
+                                                        const int32_t *__restrict__ uv, int32_t ocw, int32_t *__restrict__ counts)
+{
+    const int t = blockIdx.x;
+    const int u = uv[2 * t], v = uv[2 * t + 1];
+    const int cw = 2 * ocw + 1;
+    int bad = 0;
+    for (int q = threadIdx.x; q < cw * cw; q += blockDim.x) {
+        const int r = q / cw, c = q - r * cw;
+        bad += ((double)img[(size_t)(v - ocw + r) * W + u - ocw + c] < 0.00001) ? 1 : 0;     // :97 (f32 vs f64 constant)
+    }
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[t] = total;
+}
+
+__global__ __launch_bounds__(256) void cp_extract(const float *__restrict__ img, int32_t H, int32_t W, const int32_t *__restrict__ uv,
+                                                  int32_t half, float *__restrict__ atlas)
+{
+    const int t = blockIdx.x;
+    const int u = uv[2 * t], v = uv[2 * t + 1];
+    const int cs = 2 * half + 1;
+    float *tile = atlas + (size_t)t * cs * cs;
+    for (int q = threadIdx.x; q < cs * cs; q += blockDim.x) {
+        const int r = q / cs, c = q - r * cs;
+        tile[q] = img[(size_t)(v - half + r) * W + u - half + c];
+    }
+}
+
+struct ConvK { float k[9]; int32_t kh, kw; };
+
+__global__ __launch_bounds__(256) void cp_conv_min(const float *__restrict__ img, int32_t H, int32_t W, const int32_t *__restrict__ uv,
+                                                   int32_t half, ConvK kk, float *__restrict__ tmp, float *__restrict__ imin)
+{
+    const int t = blockIdx.x;
+    const int u = uv[2 * t], v = uv[2 * t + 1];
+    const int ts = 2 * half + 3, h1 = half + 1;
+    const int ox = kk.kw / 2, oy = kk.kh / 2;
+    float *plane = tmp + (size_t)t * ts * ts;
+    float mn = 1e+37f;
+    for (int q = threadIdx.x; q < ts * ts; q += blockDim.x) {
+        const int r = q / ts, c = q - r * ts;
+        if (r < oy || r >= ts - oy || c < ox || c >= ts - ox) continue;
+        float s = 0.0f;
+        for (int i = 0; i < kk.kh; i++)
+            for (int j = 0; j < kk.kw; j++) {
+                const float p = img[(size_t)(v - h1 + r + i - oy) * W + u - h1 + c + j - ox];
+                const float dn = ((int32_t)((double)p + 0.5) != 0) ? p : __builtin_nanf("");      // :2545
+                s += dn * kk.k[i * kk.kw + j];
+            }
+        plane[q] = s;
+        if (s < mn) mn = s;                                                   // false for NaN (:2559)
+    }
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) mn = part[w] < mn ? part[w] : mn;
+        imin[t] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void cp_shift_copy(const float *__restrict__ tmp, const float *__restrict__ mnv, int32_t half,
+                                                     float *__restrict__ atlas)
+{
+    const int t = blockIdx.x;
+    const int cs = 2 * half + 1, ts = cs + 2;
+    const float mn = mnv[t];
+    const float *plane = tmp + (size_t)t * ts * ts;
+    float *tile = atlas + (size_t)t * cs * cs;
+    for (int q = threadIdx.x; q < cs * cs; q += blockDim.x) {
+        const int r = q / cs, c = q - r * cs;
+        const float x = plane[(r + 1) * ts + c + 1];
+        tile[q] = (x != x) ? 0.0f : x - (mn - 1.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void negate_uv(float *out, int32_t n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[3 * (size_t)i] = -out[3 * (size_t)i];
+    out[3 * (size_t)i + 1] = -out[3 * (size_t)i + 1];
+}
+
+}  // namespace
+
+hipError_t launch_cp_count_invalid(const float *img, int32_t H, int32_t W, const int32_t *uv, int32_t n, int32_t ocw, int32_t *counts,
+                                   hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cp_count_invalid, dim3(n), dim3(256), 0, stream, img, H, W, uv, ocw, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_cp_extract(const float *img, int32_t H, int32_t W, const int32_t *uv, int32_t n, int32_t half, float *atlas,
+                             hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cp_extract, dim3(n), dim3(256), 0, stream, img, H, W, uv, half, atlas);
+    return hipGetLastError();
+}
+
+hipError_t launch_cp_conv_min(const float *img, int32_t H, int32_t W, const int32_t *uv, int32_t n, int32_t half, const float *k,
+                              int32_t kh, int32_t kw, float *tmp, float *imin, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    if (kh < 1 || kw < 1 || kh > 3 || kw > 3) return hipErrorInvalidValue;
+    ConvK kk{};
+    kk.kh = kh; kk.kw = kw;
+    for (int i = 0; i < kh * kw; i++) kk.k[i] = k[i];
+    hipLaunchKernelGGL(cp_conv_min, dim3(n), dim3(256), 0, stream, img, H, W, uv, half, kk, tmp, imin);
+    return hipGetLastError();
+}
+
+hipError_t launch_cp_shift_copy(const float *tmp, const float *mn, int32_t n, int32_t half, float *atlas, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cp_shift_copy, dim3(n), dim3(256), 0, stream, tmp, mn, half, atlas);
+    return hipGetLastError();
+}
+
+hipError_t launch_negate_uv(float *out, int32_t n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(negate_uv, dim3((n + 255) / 256), dim3(256), 0, stream, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace mimc3

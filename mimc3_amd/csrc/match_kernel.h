@@ -17,6 +17,8 @@ struct MatchArgs {
     const int64_t *piv_off;      // device CSR offsets [N+1]
     int32_t ocw;
     int32_t swap;                // 0: chip from i0, window from i1; 1: exchanged
+    int32_t win_half;            // 0: DLC window (|last pivot|+ocw+2, last row/column empty, :863-886); >0: the search area is
+                                 // the full (2*win_half+1)^2 square (get_offset_image's image chips, :347)
     float thr;                   // smallest f32 whose f64 value is >= MIN_DN (1e-10, MIMC_module.c:21)
     float *out;                  // device [N][3]
     const int32_t *point_list;   // optional: process only these point indices (device list) ...

@@ -121,6 +121,7 @@ __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, un
         g.dx2 = (lu < 0 ? -lu : lu) + p.ocw + 2;
         g.dy2 = (lv < 0 ? -lv : lv) + p.ocw + 2;
     }
+    if (p.win_half > 0) { g.dx2 = p.win_half; g.dy2 = p.win_half; }
     g.Dx2 = 2 * g.dx2 + 1; g.Dy2 = 2 * g.dy2 + 1;
     g.csx = g.Dx2 - 2 * g.ocw + 1; g.csy = g.Dy2 - 2 * g.ocw + 1;
     const int ncell = g.csx * g.csy;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, un
     Win<WIN_LDS> win;
     win.lds = wlds; win.img = win_img; win.H = p.H; win.W = p.W; win.Dx2 = g.Dx2;
     win.u_org = u0 + p.off_u - g.dx2; win.v_org = v0 + p.off_v - g.dy2;
-    win.lim_x = 2 * g.dx2; win.lim_y = 2 * g.dy2;
+    win.lim_x = 2 * g.dx2 + (p.win_half > 0 ? 1 : 0); win.lim_y = 2 * g.dy2 + (p.win_half > 0 ? 1 : 0);
     {
         const int nwin = g.Dx2 * g.Dy2;
         for (int q = tid; q < nwin; q += kMatchThreads) {
@@ -366,10 +367,10 @@ hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_n
     static bool attr_set = false;
     const size_t kLdsCap = 160 * 1024;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
         attr_set = true;
     }
     bool win_lds = true;

@@ -181,10 +181,16 @@ static void find_peak(const float *chip, int ocw, const float *win, int Dx2, int
     cp[4] = -6 * n9[0] - 6 * n9[1] - 6 * n9[2] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
     cp[5] = -4 * n9[0] + 8 * n9[1] - 4 * n9[2] + 8 * n9[3] + 20 * n9[4] + 8 * n9[5] - 4 * n9[6] + 8 * n9[7] - 4 * n9[8];
     for (int i = 0; i < 6; i++) cp[i] /= 36;
-    uvncc0 = -2 * cp[2] * cp[3] + cp[1] * cp[4];
-    uvncc1 = -2 * cp[0] * cp[4] + cp[1] * cp[3];
+    /* The reference stores each step into a float (:782-788), i.e. the numerator is rounded to f32 BEFORE the f64
+     * division.  gcc 11 -O3's SLP vectoriser has been seen to fuse the pair of statements below and drop that
+     * rounding (1 ulp off on golden `edge_windows`), hence the volatile stores (and -fno-tree-slp-vectorize). */
+    volatile float q0 = -2 * cp[2] * cp[3] + cp[1] * cp[4];
+    volatile float q1 = -2 * cp[0] * cp[4] + cp[1] * cp[3];
+    uvncc0 = q0; uvncc1 = q1;
     uvncc0 /= 4 * cp[0] * cp[2] - cp[1] * cp[1];
     uvncc1 /= 4 * cp[0] * cp[2] - cp[1] * cp[1];
+    q0 = uvncc0; q1 = uvncc1;
+    uvncc0 = q0; uvncc1 = q1;
     uvncc0 += (float)(peak_u - w.dx2);
     uvncc1 += (float)(peak_v - w.dy2);
     out3[0] = uvncc0; out3[1] = uvncc1; out3[2] = best;

@@ -120,6 +120,22 @@ def main():
     np.savez_compressed(os.path.join(OUT, "conv2_nulls.npz"), **d)
     print("conv2_nulls:", {n: (float(d["out_" + n].min()), float(d["out_" + n].max())) for n in ks})
 
+    # N4: control-point offset on a small pair (dense grid so that there are enough slow candidates), shuffle seed pinned
+    h, w, dimx, dimy = 260, 300, 14, 11
+    i0, i1 = synth.make_pair(h, w, (2, -3), seed=77, null_frac=0.04, noise_dn=3)
+    xy = synth.make_grid(dimx, dimy, 50, 50, 15, 15, 1806.0, angle_deg=30.0)
+    rng = np.random.default_rng(77)
+    slow = rng.random(dimx * dimy) < 0.8
+    xy[slow, 4] = rng.uniform(-5, 5, slow.sum()); xy[slow, 5] = rng.uniform(-5, 5, slow.sum())
+    par = dict(vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500, num_cp_min=10, ratio_cp=0.1, thres_spd_cp=10.0)
+    d = dict(i0=i0.astype(np.uint8), i1=i1.astype(np.uint8), xyuvav=xy, seeds=np.array([5, 1234], np.int64),
+             **{k: np.array(v) for k, v in par.items()})
+    for sd in (5, 1234):
+        rc, off, flag, _, _ = ref.get_offset_image(i0, i1, xy, list(ks.values()), sd, **par)
+        d[f"rc_{sd}"] = np.int32(rc); d[f"offset_{sd}"] = off; d[f"flag_{sd}"] = flag
+        print(f"cp_small seed {sd}: rc={rc} offset={off.tolist()} cps={int(flag.sum())}")
+    np.savez_compressed(os.path.join(OUT, "cp_small.npz"), **d)
+
 
 if __name__ == "__main__":
     main()

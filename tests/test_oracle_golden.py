@@ -57,3 +57,22 @@ def test_conv2_golden(oracle, path):
     img = z["img"].astype(np.float32)
     for name in ("ddx", "ddy", "laplacian"):
         assert_bits_equal(oracle.float_conv2(img, z["k_" + name]), z["out_" + name], name)
+
+
+def _cp_golden():
+    z = np.load(golden_files("cp_small")[0])
+    par = dict(vec_ocw=tuple(int(v) for v in z["vec_ocw"]), aw_cre=float(z["aw_cre"]), num_cp_max=int(z["num_cp_max"]),
+               num_cp_min=int(z["num_cp_min"]), ratio_cp=float(z["ratio_cp"]), thres_spd_cp=float(z["thres_spd_cp"]))
+    ks = [np.array([[-1, 0, 1]], np.float32), np.array([[-1], [0], [1]], np.float32),
+          np.array([[-1 / 8] * 3, [-1 / 8, 1, -1 / 8], [-1 / 8] * 3], np.float32)]
+    return z, par, ks
+
+
+def test_cp_offset_golden(oracle):
+    """N4: get_offset_image with the shuffle seed pinned -- status, offset and the control-point flags"""
+    z, par, ks = _cp_golden()
+    i0, i1 = z["i0"].astype(np.float32), z["i1"].astype(np.float32)
+    for sd in z["seeds"]:
+        rc, off, flag, info, _ = oracle.get_offset_image(i0, i1, z["xyuvav"], ks, int(sd), **par)
+        assert rc == int(z[f"rc_{sd}"]) and np.array_equal(off, z[f"offset_{sd}"]) and np.array_equal(flag, z[f"flag_{sd}"])
+        assert info[3] == flag.sum() > 0

@@ -89,3 +89,27 @@ def test_conv2_vs_reference(oracle, reference):
         assert_bits_equal(oracle.float_conv2(img, k), reference.float_conv2(img, k), f"k{k.shape}")
         dirty = rng.uniform(-50, 50, img.shape).astype(np.float32)
         assert_bits_equal(oracle.float_conv2(img, k, dirty), reference.float_conv2(img, k, dirty), f"k{k.shape} dirty")
+
+
+@pytest.mark.parametrize("kw", [dict(seed=1, shift=(2, -1)), dict(seed=2, shift=(-3, 4), null_frac=0.05, noise=2),
+                                dict(seed=6, shift=(-1, 1), null_frac=0.5, noise=40, slow=0.9, tear=True),
+                                dict(seed=4, shift=(5, 5), slow=0.05)], ids=lambda k: f"seed{k['seed']}")
+def test_cp_offset_vs_reference(oracle, reference, kw):
+    """get_offset_image (:33-492), srand seed pinned through the harness's wrapped time()"""
+    kw = dict(kw)
+    tear = kw.pop("tear", False)
+    noise = kw.pop("noise", 0)
+    slow = kw.pop("slow", 0.7)
+    i0, i1 = synth.make_pair(620, 700, kw["shift"], seed=kw["seed"], null_frac=kw.get("null_frac", 0.0), noise_dn=noise)
+    xy = synth.make_grid(24, 20, 60, 60, 24, 25, 1806.0, angle_deg=30.0)
+    rng = np.random.default_rng(kw["seed"])
+    s = rng.random(480) < slow
+    xy[s, 4] = rng.uniform(-5, 5, s.sum()); xy[s, 5] = rng.uniform(-5, 5, s.sum())
+    if tear:
+        i1 = i1.copy(); i1[:300, :350] = np.roll(i1[:300, :350], 3, axis=1)
+    ks = [np.array([[-1, 0, 1]], np.float32), np.array([[-1], [0], [1]], np.float32),
+          np.array([[-1 / 8] * 3, [-1 / 8, 1, -1 / 8], [-1 / 8] * 3], np.float32)]
+    for sd in (3, 99):
+        a = reference.get_offset_image(i0, i1, xy, ks, sd, num_cp_min=20)
+        b = oracle.get_offset_image(i0, i1, xy, ks, sd, num_cp_min=20)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
