@@ -156,8 +156,10 @@ int mimc3_float_conv2(mimc3_ctx *ctx, const float *in, int32_t H, int32_t W, con
 int mimc3_float_conv2_dev(mimc3_ctx *ctx, const float *d_in, int32_t H, int32_t W, const float *kernel /*host*/,
                           int32_t kh, int32_t kw, float *d_out, void *d_scratch, void *stream);
 /*      Filter the context's resident pair on the device and make the filtered pair the one the matcher uses
- *      (what MIMC_main.c:304-350 does with host copies for its 24 filtered passes); output planes start as
- *      zeros.  kernel = NULL goes back to the pair as handed over.  Nothing crosses PCIe.
+ *      (what MIMC_main.c:302-350 does with host copies for its 24 filtered passes).  Like the reference, the two
+ *      output planes are created once per pair (zeros) and REUSED by consecutive calls, so the border a filter
+ *      leaves behind is input to the next one; mimc3_ctx_set_images* starts over.  kernel = NULL goes back to
+ *      the pair as handed over.  Nothing crosses PCIe.
  *      mimc3_ctx_get_images downloads the pair currently in use (either pointer may be NULL). --------- */
 int mimc3_ctx_filter_images(mimc3_ctx *ctx, const float *kernel, int32_t kh, int32_t kw);
 int mimc3_ctx_get_images(mimc3_ctx *ctx, float *i0, float *i1);
@@ -183,6 +185,57 @@ typedef struct mimc3_cp_params {
 int mimc3_get_offset_image(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_cp_params *params,
                            int32_t offset[2], uint8_t *flag_cp, int32_t *status, int32_t *info /*[4]*/,
                            float *sduv /*[2]*/);
+
+/* ---- N3: the program's data path on arrays ---------------------------------------------------------------
+ *      mimc3_postprocess replaces mimc2_postprocess (MIMC_module.h:48, MIMC_module.c:892-990): clustering ->
+ *      dpf0 (ratio 0.6) -> dpf1 (radius_dpf1) -> QM pseudo-smoothing (radius_ps, qm_max_sweeps: 101 = reference)
+ *      -> out5 [5][dimy*dimx] = mean_u, mean_v, var_u, var_v, fraction of the chosen cluster, NaN where none
+ *      (the reference's vxyexyqual[0..4] BEFORE main()'s unit conversion).  dp = [ndp][N][3] pass-major.
+ *      _dev: d_dp, d_xyuvav, d_out5 on the device; xyuvav also on the host (neighbour geometry is host code);
+ *      synchronises `stream` (data-dependent sweep counts, temporary buffers). ------------------------------ */
+int mimc3_postprocess(mimc3_ctx *ctx, const float *dp, int32_t ndp, const double *xyuvav, int32_t dimx, int32_t dimy,
+                      float dt, float mpp, float meter_per_spacing, float radius_dpf1, float radius_ps,
+                      int32_t qm_max_sweeps, float *out5);
+int mimc3_postprocess_dev(mimc3_ctx *ctx, const float *d_dp, int32_t ndp, const double *xyuvav, const double *d_xyuvav,
+                          int32_t dimx, int32_t dimy, float dt, float mpp, float meter_per_spacing, float radius_dpf1,
+                          float radius_ps, int32_t qm_max_sweeps, float *d_out5, void *stream);
+
+/*      mimc3_vmap = MIMC_main.c:203-402, from "xyuvav and both images loaded" to "save the output", on the
+ *      context's resident pair: grid geometry (:209-223), CP offset (:240-256), the 32 matcher passes
+ *      (:261-350; pivots, images, candidates never leave the device), mimc2_postprocess (:353), removal of the
+ *      sub-integer CP offset and px -> m/yr (:356-402).  Outputs [dimy*dimx] f32 as the reference saves them:
+ *      vx, vy (m/yr, vy north-positive), ex, ey (m/yr), qual; flag_cp [N] bytes.  res->cp_status = -1 means
+ *      "not enough control points": nothing else is computed (the CLI then touches vmap_*.tar, :248-252). --- */
+typedef struct mimc3_vmap_params {
+    int32_t vec_ocw[4];                 /* MIMC_main.c:134-137: 7, 15, 30, 40                        */
+    float aw_cre, aw_sf;                /* :154-155: 10.0, 1.8                                        */
+    float radius_neighbor_dpf1;         /* :164: 1000/300 = 3 (grid spacings)                         */
+    float radius_neighbor_ps;           /* :165: 5.0                                                  */
+    int32_t num_cp_max, num_cp_min;     /* :168-169: 500, 50                                          */
+    float ratio_cp, thres_spd_cp;       /* :170-171: 0.03, 10                                         */
+    const float *kernel[3];             /* :176-194: d/dx 1x3, d/dy 3x1, Laplacian 3x3, row-major     */
+    int32_t kdim[3][2];
+    int64_t cp_seed;                    /* shuffle seed of the CP stage; < 0 = time(NULL)             */
+    int32_t qm_max_sweeps;              /* 0 or 101 = reference                                        */
+} mimc3_vmap_params;
+typedef struct mimc3_vmap_result {
+    int32_t dimx, dimy;
+    float mpp, spacing_grid, meter_per_spacing;
+    int32_t cp_status;                  /* 1 ok, -1 not enough control points                         */
+    int32_t offset_cp[2];               /* integer CP offset (meta: cp_offset_int_u/v)                */
+    float cp_subint[2];                 /* grid mean removed afterwards (meta: cp_offset_subint_u/v)  */
+} mimc3_vmap_result;
+int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params,
+               float *vx, float *vy, float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res);
+
+/*      small device helpers the driver is built from: the context's own stream; (du,dv) -> (-du,-dv) of a swapped
+ *      pass (MIMC_main.c:289-293); cluster map -> five planes (mimc2_postprocess :937-970 /
+ *      convert_dpf_to_vxy_exy_qual, MIMC_module.h:64); size of the resident pair. --------------------------- */
+void *mimc3_ctx_stream(mimc3_ctx *ctx);
+int mimc3_negate_uv_dev(mimc3_ctx *ctx, float *d_out, int32_t N, void *stream);
+int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *ctx, const int32_t *d_dpf, const float *d_mvn, int32_t N, int32_t Kmax,
+                                float *d_out5, void *stream);
+int mimc3_ctx_image_size(mimc3_ctx *ctx, int32_t *H, int32_t *W);
 
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */

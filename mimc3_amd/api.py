@@ -77,6 +77,28 @@ class CpParams(C.Structure):
 
 _lib.mimc3_get_offset_image.argtypes = [_vp, _f64p, C.c_int32, C.POINTER(CpParams), _i32p,
                                         np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(C.c_int32), _i32p, _f32p]
+
+
+class VmapParams(C.Structure):
+    """mimc3_vmap_params: the reference's `param_mimc2` + kernels (defaults = MIMC_main.c:134-194)."""
+    _fields_ = [("vec_ocw", C.c_int32 * 4), ("aw_cre", C.c_float), ("aw_sf", C.c_float), ("radius_neighbor_dpf1", C.c_float),
+                ("radius_neighbor_ps", C.c_float), ("num_cp_max", C.c_int32), ("num_cp_min", C.c_int32), ("ratio_cp", C.c_float),
+                ("thres_spd_cp", C.c_float), ("kernel", C.c_void_p * 3), ("kdim", (C.c_int32 * 2) * 3), ("cp_seed", C.c_int64),
+                ("qm_max_sweeps", C.c_int32)]
+
+
+class VmapResult(C.Structure):
+    _fields_ = [("dimx", C.c_int32), ("dimy", C.c_int32), ("mpp", C.c_float), ("spacing_grid", C.c_float),
+                ("meter_per_spacing", C.c_float), ("cp_status", C.c_int32), ("offset_cp", C.c_int32 * 2), ("cp_subint", C.c_float * 2)]
+
+
+CLI_KERNELS = (np.array([[-1, 0, 1]], np.float32), np.array([[-1], [0], [1]], np.float32),
+               np.array([[-1 / 8] * 3, [-1 / 8, 1, -1 / 8], [-1 / 8] * 3], np.float32))     # MIMC_main.c:176-194
+
+_lib.mimc3_postprocess.argtypes = [_vp, _f32p, C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int32, _f32p]
+_lib.mimc3_vmap.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), _f32p, _f32p, _f32p, _f32p, _f32p,
+                            np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(VmapResult)]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
@@ -218,6 +240,43 @@ class Context:
                                     max_sweeps, d_work, d_sweeps=None, stream=0):
         _check(_lib.mimc3_qm_pseudosmooth_dev(self._h, dimy, dimx, d_dpf, d_dx, d_dy, d_ruv, nn, d_mvn, kmax, d_nclus,
                                               d_xyuvav, max_sweeps, d_work, d_sweeps, stream), "get_dpf_pseudosmoothing_dev")
+
+    # -- N3: the program's data path on arrays -----------------------------------------------------
+    def mimc2_postprocess(self, dp, xyuvav, dimx, dimy, dt, mpp, meter_per_spacing, radius_dpf1=3.0, radius_ps=5.0,
+                          qm_max_sweeps=101):
+        """mimc2_postprocess (MIMC_module.c:892-990): dp [ndp][N][3] -> vxyexyqual [5][dimy][dimx] (px units)."""
+        dp = np.ascontiguousarray(dp, np.float32)
+        out = np.empty((5, dimy, dimx), np.float32)
+        _check(_lib.mimc3_postprocess(self._h, dp, dp.shape[0], np.ascontiguousarray(xyuvav, np.float64), dimx, dimy, dt, mpp,
+                                      meter_per_spacing, radius_dpf1, radius_ps, qm_max_sweeps, out.reshape(-1)), "mimc2_postprocess")
+        return out
+
+    def vmap(self, xyuvav, dt, kernels=CLI_KERNELS, cp_seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, aw_sf=1.8,
+             radius_neighbor_dpf1=3.0, radius_neighbor_ps=5.0, num_cp_max=500, num_cp_min=50, ratio_cp=0.03, thres_spd_cp=10.0,
+             qm_max_sweeps=101):
+        """MIMC_main.c:203-402 on the resident pair. Returns dict(vx, vy, ex, ey, qual [dimy][dimx], flag_cp, + the
+        scalar fields of mimc3_vmap_result); arrays are None when cp_status == -1."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        n = xy.shape[0]
+        ks = [np.ascontiguousarray(k, np.float32) for k in kernels]
+        p = VmapParams()
+        p.vec_ocw[:] = list(vec_ocw)
+        p.aw_cre = aw_cre; p.aw_sf = aw_sf; p.radius_neighbor_dpf1 = radius_neighbor_dpf1; p.radius_neighbor_ps = radius_neighbor_ps
+        p.num_cp_max = num_cp_max; p.num_cp_min = num_cp_min; p.ratio_cp = ratio_cp; p.thres_spd_cp = thres_spd_cp
+        p.cp_seed = cp_seed; p.qm_max_sweeps = qm_max_sweeps
+        for i, k in enumerate(ks):
+            p.kernel[i] = k.ctypes.data
+            p.kdim[i][0], p.kdim[i][1] = k.shape
+        planes = [np.empty(n, np.float32) for _ in range(5)]
+        flag = np.zeros(n, np.uint8)
+        r = VmapResult()
+        _check(_lib.mimc3_vmap(self._h, xy, n, dt, C.byref(p), *planes, flag, C.byref(r)), "vmap")
+        out = dict(dimx=r.dimx, dimy=r.dimy, mpp=r.mpp, spacing_grid=r.spacing_grid, meter_per_spacing=r.meter_per_spacing,
+                   cp_status=r.cp_status, offset_cp=(r.offset_cp[0], r.offset_cp[1]), cp_subint=(r.cp_subint[0], r.cp_subint[1]),
+                   flag_cp=flag)
+        for name, a in zip(("vx", "vy", "ex", "ey", "qual"), planes):
+            out[name] = a.reshape(r.dimy, r.dimx) if r.cp_status > 0 else None
+        return out
 
     # -- N4: control-point offset -----------------------------------------------------------------
     def get_offset_image(self, xyuvav, kernels, seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500, num_cp_min=50,

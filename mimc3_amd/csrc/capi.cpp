@@ -75,6 +75,7 @@ struct mimc3_ctx {
     const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
     DevBuf filt0, filt1, conv_io;       // pre-filtered pair (mimc3_ctx_filter_images), conv2 staging
     DevBuf cp_buf;                      // control-point stage: one arena carved per call
+    bool filt_live = false;             // filt0/filt1 hold the output planes of an earlier filter pass on this pair
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -201,14 +202,14 @@ extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->d_i0 = c->raw_i0 = static_cast<const float *>(c->own_i0.p);
     c->d_i1 = c->raw_i1 = static_cast<const float *>(c->own_i1.p);
-    c->H = H; c->W = W;
+    c->H = H; c->W = W; c->filt_live = false;
     return prepare_u8(c);
 }
 
 extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
 {
     if (!c || !d_i0 || !d_i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_dev: bad argument");
-    c->d_i0 = c->raw_i0 = d_i0; c->d_i1 = c->raw_i1 = d_i1; c->H = H; c->W = W;
+    c->d_i0 = c->raw_i0 = d_i0; c->d_i1 = c->raw_i1 = d_i1; c->H = H; c->W = W; c->filt_live = false;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());   // the caller's producer stream is unknown: make the pixels visible
     return prepare_u8(c);
@@ -636,9 +637,15 @@ extern "C" int mimc3_ctx_filter_images(mimc3_ctx *c, const float *kernel, int32_
     HIP_TRY(c->filt1.reserve(bytes));
     HIP_TRY(c->conv_io.reserve(256));
     hipStream_t s = c->stream;
-    // the reference filters into freshly malloc'ed planes whose border it never writes (MIMC_main.c:304-312): zeros (T4)
-    HIP_TRY(hipMemsetAsync(c->filt0.p, 0, bytes, s));
-    HIP_TRY(hipMemsetAsync(c->filt1.p, 0, bytes, s));
+    // The reference allocates its two output planes ONCE (MIMC_main.c:302-303: fresh memory, zeros -- T4) and runs all
+    // three filters into them (:306-307).  GMA_float_conv2 never writes the border of `out` but reads it (minimum,
+    // right-hand columns of the shift), so what one filter leaves in the border rows/columns is input to the next:
+    // the planes are cleared only for the first filter after the pair was set.
+    if (!c->filt_live) {
+        HIP_TRY(hipMemsetAsync(c->filt0.p, 0, bytes, s));
+        HIP_TRY(hipMemsetAsync(c->filt1.p, 0, bytes, s));
+        c->filt_live = true;
+    }
     int rc = mimc3_float_conv2_dev(c, c->raw_i0, c->H, c->W, kernel, kh, kw, static_cast<float *>(c->filt0.p), c->conv_io.p, s);
     if (rc) return rc;
     rc = mimc3_float_conv2_dev(c, c->raw_i1, c->H, c->W, kernel, kh, kw, static_cast<float *>(c->filt1.p), c->conv_io.p, s);
@@ -876,5 +883,37 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     offset[0] = du > 0 ? (int32_t)(du + 0.5) : (int32_t)(du - 0.5);
     offset[1] = dv > 0 ? (int32_t)(dv + 0.5) : (int32_t)(dv - 0.5);
     *status = 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers used by the whole-program driver (pipeline.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" void *mimc3_ctx_stream(mimc3_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+extern "C" int mimc3_negate_uv_dev(mimc3_ctx *c, float *d_out, int32_t N, void *stream)
+{
+    if (!c || !d_out || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_negate_uv_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = mimc3::launch_negate_uv(d_out, N, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "negate kernel launch");
+    return 0;
+}
+
+extern "C" int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *c, const int32_t *d_dpf, const float *d_mvn, int32_t N, int32_t Kmax,
+                                           float *d_out5, void *stream)
+{
+    if (!c || !d_dpf || !d_mvn || !d_out5 || N <= 0 || Kmax <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_dpf_to_vxyexyqual_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = mimc3::launch_gather(d_dpf, d_mvn, N, Kmax, d_out5, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "gather kernel launch");
+    return 0;
+}
+
+extern "C" int mimc3_ctx_image_size(mimc3_ctx *c, int32_t *H, int32_t *W)
+{
+    if (!c || !H || !W) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_image_size: bad argument");
+    if (!c->raw_i0) return mimc3::fail(MIMC3_ESTATE, "mimc3_ctx_image_size: images not set");
+    *H = c->H; *W = c->W;
     return 0;
 }

@@ -21,6 +21,9 @@ hipError_t launch_cluster(ClusterArgs a, hipStream_t stream);
 hipError_t launch_dpf0(const float *mvn, const int32_t *nclus, int32_t N, int32_t Kmax, float min_ratio,
                        int32_t *dpf, hipStream_t stream);
 
+// out5 [5][N] = (mean_u, mean_v, var_u, var_v, fraction) of the chosen cluster, NaN where dpf < 0
+hipError_t launch_gather(const int32_t *dpf, const float *mvn, int32_t N, int32_t Kmax, float *out5, hipStream_t stream);
+
 // dpf1 state words (device)
 enum { kD1ThresNum = 0, kD1Done = 1, kD1Sweeps = 2, kD1Tally = 4 /* u64: ticket | processed | unprocessed */, kD1Words = 8 };
 constexpr int kD1SweepThreads = 256;

@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256) void dpf0_kernel(const float *__restrict__ mvn
     dpf[g] = id;
 }
 
+// cluster map -> the five output planes (mimc2_postprocess :937-970 / convert_dpf_to_vxy_exy_qual :2498-2515)
+__global__ __launch_bounds__(256) void gather_kernel(const int32_t *__restrict__ dpf, const float *__restrict__ mvn, int32_t N,
+                                                     int32_t Kmax, float *__restrict__ out5)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const int id = dpf[g];
+    const float nanv = __builtin_nanf("");
+#pragma unroll
+    for (int k = 0; k < 5; k++) out5[(size_t)k * N + g] = id >= 0 ? mvn[((size_t)g * Kmax + id) * 5 + k] : nanv;
+}
+
 __device__ __forceinline__ float sqrt_f(float s) { return (float)sqrt((double)s); }  // C: sqrt(float) is the f64 sqrt
 
 // Per-point terms of get_dpf1's neighbour table (:1421-1448) that depend only on the neighbour h itself:
@@ -355,6 +367,12 @@ hipError_t launch_dpf0(const float *mvn, const int32_t *nclus, int32_t N, int32_
                        hipStream_t stream)
 {
     hipLaunchKernelGGL(dpf0_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, mvn, nclus, N, Kmax, min_ratio, dpf);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const int32_t *dpf, const float *mvn, int32_t N, int32_t Kmax, float *out5, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dpf, mvn, N, Kmax, out5);
     return hipGetLastError();
 }
 

@@ -1,0 +1,217 @@
+// pipeline.cpp -- the reference program's data path on resident arrays, built ONLY from the public C ABI
+// (include/mimc3_hip.h) plus the HIP runtime for buffers:
+//
+//   mimc3_postprocess[_dev]  = mimc2_postprocess (MIMC_module.c:892-990): clustering -> dpf0 -> dpf1 -> QM -> planes
+//   mimc3_vmap               = MIMC_main.c:203-402 between "xyuvav and images loaded" and "save the output":
+//                              grid geometry, CP offset, the 32 matcher passes (4 chip sizes x {raw, d/dx, d/dy,
+//                              Laplacian} x {forward, swapped}), postprocess, sub-integer CP mean removal, px -> m/yr
+//
+// Everything that touches pixels or candidates runs on the device; the host keeps what the reference does serially
+// in f32 (the mean over the grid, :362-378) so that the sums round identically.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mimc3_hip.h"
+#include "host_util.h"
+
+namespace {
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return mimc3::fail((int)e > 0 ? (int)e : MIMC3_ENODEV, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+}  // namespace
+
+#define HIP_TRY(expr)                                           \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);       \
+    } while (0)
+#define RC_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_) return rc_;        \
+    } while (0)
+
+extern "C" int mimc3_postprocess_dev(mimc3_ctx *ctx, const float *d_dp, int32_t ndp, const double *xyuvav, const double *d_xyuvav,
+                                     int32_t dimx, int32_t dimy, float dt, float mpp, float meter_per_spacing,
+                                     float radius_dpf1, float radius_ps, int32_t qm_max_sweeps, float *d_out5, void *stream)
+{
+    if (!ctx || !d_dp || !xyuvav || !d_xyuvav || !d_out5 || ndp < 1 || ndp > 64 || dimx < 1 || dimy < 1 || qm_max_sweeps < 1)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_postprocess_dev: bad argument");
+    const int32_t N = dimx * dimy, K = ndp;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // neighbour offsets for the two radii (host geometry, get_ruv_neighbor :1266-1327)
+    std::vector<int32_t> ruv1(2 * 4096), ruv2(2 * 4096);
+    int32_t nn1 = 0, nn2 = 0;
+    RC_TRY(mimc3_get_ruv_neighbor(xyuvav, N, dimx, dimy, meter_per_spacing, radius_dpf1, ruv1.data(), 4096, &nn1));
+    RC_TRY(mimc3_get_ruv_neighbor(xyuvav, N, dimx, dimy, meter_per_spacing, radius_ps, ruv2.data(), 4096, &nn2));
+    Buf mvn, ncl, kmax, dpf, dx, dy, r1, r2, w1, w2;
+    HIP_TRY(mvn.alloc(sizeof(float) * 5 * (size_t)N * K));
+    HIP_TRY(ncl.alloc(sizeof(int32_t) * (size_t)N));
+    HIP_TRY(kmax.alloc(sizeof(int32_t)));
+    HIP_TRY(dpf.alloc(sizeof(int32_t) * (size_t)N));
+    HIP_TRY(dx.alloc(sizeof(float) * (size_t)N));
+    HIP_TRY(dy.alloc(sizeof(float) * (size_t)N));
+    HIP_TRY(r1.alloc(8 * (size_t)(nn1 > 0 ? nn1 : 1)));
+    HIP_TRY(r2.alloc(8 * (size_t)(nn2 > 0 ? nn2 : 1)));
+    HIP_TRY(w1.alloc((size_t)mimc3_dpf1_workspace_bytes(N)));
+    HIP_TRY(w2.alloc((size_t)mimc3_qm_workspace_bytes(N, qm_max_sweeps)));
+    HIP_TRY(hipMemcpyAsync(r1.p, ruv1.data(), 8 * (size_t)nn1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r2.p, ruv2.data(), 8 * (size_t)nn2, hipMemcpyHostToDevice, s));
+    RC_TRY(mimc3_cluster_candidates_dev(ctx, d_dp, ndp, N, K, mvn.as<float>(), ncl.as<int32_t>(), kmax.as<int32_t>(), s));   // :904
+    RC_TRY(mimc3_get_dpf0_dev(ctx, mvn.as<float>(), ncl.as<int32_t>(), N, K, 0.6f, dpf.as<int32_t>(), s));                    // :912
+    int32_t sweeps = 0;
+    RC_TRY(mimc3_get_dpf1_dev(ctx, dimy, dimx, dpf.as<int32_t>(), dx.as<float>(), dy.as<float>(), r1.as<int32_t>(), nn1, mvn.as<float>(), K,
+                              ncl.as<int32_t>(), d_xyuvav, dt, mpp, w1.p, &sweeps, s));                                         // :926
+    RC_TRY(mimc3_qm_pseudosmooth_dev(ctx, dimy, dimx, dpf.as<int32_t>(), dx.as<float>(), dy.as<float>(), r2.as<int32_t>(), nn2,
+                                     mvn.as<float>(), K, ncl.as<int32_t>(), d_xyuvav, qm_max_sweeps, w2.p, nullptr, s));        // :933
+    RC_TRY(mimc3_dpf_to_vxyexyqual_dev(ctx, dpf.as<int32_t>(), mvn.as<float>(), N, K, d_out5, s));                             // :937-970
+    HIP_TRY(hipStreamSynchronize(s));       // the buffers above are freed on return
+    return 0;
+}
+
+extern "C" int mimc3_postprocess(mimc3_ctx *ctx, const float *dp, int32_t ndp, const double *xyuvav, int32_t dimx, int32_t dimy,
+                                 float dt, float mpp, float meter_per_spacing, float radius_dpf1, float radius_ps,
+                                 int32_t qm_max_sweeps, float *out5)
+{
+    if (!ctx || !dp || !xyuvav || !out5 || ndp < 1 || dimx < 1 || dimy < 1) return mimc3::fail(MIMC3_EINVAL, "mimc3_postprocess: bad argument");
+    const size_t N = (size_t)dimx * dimy;
+    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+    Buf d_dp, d_xy, d_o;
+    HIP_TRY(d_dp.alloc(12 * N * ndp));
+    HIP_TRY(d_xy.alloc(48 * N));
+    HIP_TRY(d_o.alloc(20 * N));
+    HIP_TRY(hipMemcpyAsync(d_dp.p, dp, 12 * N * ndp, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * N, hipMemcpyHostToDevice, s));
+    RC_TRY(mimc3_postprocess_dev(ctx, d_dp.as<float>(), ndp, xyuvav, d_xy.as<double>(), dimx, dimy, dt, mpp, meter_per_spacing, radius_dpf1,
+                                 radius_ps, qm_max_sweeps, d_o.as<float>(), s));
+    HIP_TRY(hipMemcpyAsync(out5, d_o.p, 20 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, float *vx, float *vy,
+                          float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res)
+{
+    if (!ctx || !xyuvav || !p || !vx || !vy || !ex || !ey || !qual || !flag_cp || !res || N < 2)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: bad argument");
+    int32_t H = 0, W = 0;
+    RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
+    std::memset(res, 0, sizeof(*res));
+    // ---- grid geometry (MIMC_main.c:209-223)
+    int32_t g = 1;
+    for (; g < N; g++)
+        if ((int)xyuvav[6 * (size_t)g + 2] == (int)xyuvav[2]) break;
+    const int32_t dimx = g, dimy = N / dimx;
+    res->dimx = dimx; res->dimy = dimy;
+    res->mpp = (float)((xyuvav[6] - xyuvav[0]) / (xyuvav[8] - xyuvav[2]));
+    res->spacing_grid = (float)(xyuvav[8] - xyuvav[2]);
+    res->meter_per_spacing = (float)(xyuvav[6] - xyuvav[0]);
+    if (dimx * dimy != N) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: xyuvav is not a full dimy x dimx grid");
+
+    // ---- CP offset (:240-256)
+    mimc3_cp_params cp{};
+    for (int k = 0; k < 4; k++) cp.vec_ocw[k] = p->vec_ocw[k];
+    cp.aw_cre = p->aw_cre; cp.num_cp_max = p->num_cp_max; cp.num_cp_min = p->num_cp_min;
+    cp.ratio_cp = p->ratio_cp; cp.thres_spd_cp = p->thres_spd_cp; cp.seed = p->cp_seed;
+    for (int k = 0; k < 3; k++) { cp.kernel[k] = p->kernel[k]; cp.kdim[k][0] = p->kdim[k][0]; cp.kdim[k][1] = p->kdim[k][1]; }
+    std::memset(flag_cp, 0, (size_t)N);
+    int32_t off[2] = {0, 0}, st = -1;
+    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+    RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
+    res->cp_status = st;
+    if (st < 0) return 0;                                   // the CLI touches vmap.tar and gives up (:248-252)
+    res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1];
+
+    // ---- the reference refuses nothing, it reads out of bounds; this library refuses (see mimc3_match_ncc_dlc)
+    int ocw_max = 0;
+    for (int k = 0; k < 4; k++) ocw_max = p->vec_ocw[k] > ocw_max ? p->vec_ocw[k] : ocw_max;
+    for (int32_t i = 0; i < N; i++) {
+        const int32_t u0 = (int32_t)xyuvav[6 * (size_t)i + 2], v0 = (int32_t)xyuvav[6 * (size_t)i + 3];
+        if (u0 - ocw_max < 0 || u0 + ocw_max >= W || v0 - ocw_max < 0 || v0 + ocw_max >= H)
+            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: grid point " + std::to_string(i) + " chip leaves the image");
+    }
+
+    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+    const size_t n = (size_t)N;
+    Buf d_xy, d_dp, d_out5;
+    HIP_TRY(d_xy.alloc(48 * n));
+    HIP_TRY(d_dp.alloc(12 * n * 32));
+    HIP_TRY(d_out5.alloc(20 * n));
+    HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
+
+    // ---- pivots per chip size (:264, :316), forward and negated (:272-279), resident for all four image variants
+    struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; };
+    Piv piv[4];
+    for (int c = 0; c < 4; c++) {
+        std::vector<int64_t> po(n + 1);
+        int64_t total = 0;
+        RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po.data(), nullptr, 0, &total));
+        std::vector<int32_t> pu(2 * (size_t)total), pn(2 * (size_t)total);
+        RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po.data(), pu.data(), total, &total));
+        RC_TRY(mimc3_pivot_extent(pu.data(), po.data(), N, &piv[c].mn, &piv[c].mu, &piv[c].mv));
+        for (size_t i = 0; i < pu.size(); i++) pn[i] = -pu[i];
+        HIP_TRY(piv[c].uv.alloc(4 * pu.size()));
+        HIP_TRY(piv[c].uvn.alloc(4 * pn.size()));
+        HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
+        HIP_TRY(hipMemcpyAsync(piv[c].uv.p, pu.data(), 4 * pu.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(piv[c].uvn.p, pn.data(), 4 * pn.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(piv[c].off.p, po.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                   // the host vectors go out of scope
+    }
+
+    // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
+    for (int kk = -1; kk <= 2; kk++) {
+        if (kk >= 0) RC_TRY(mimc3_ctx_filter_images(ctx, p->kernel[kk], p->kdim[kk][0], p->kdim[kk][1]));
+        for (int c = 0; c < 4; c++) {
+            const int slot = (kk + 1) * 8 + c * 2;
+            float *fw = d_dp.as<float>() + (size_t)slot * n * 3, *sw = fw + n * 3;
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), N, off[0], off[1], piv[c].uv.as<int32_t>(), piv[c].off.as<int64_t>(),
+                                           piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 0, fw, s));
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), N, -off[0], -off[1], piv[c].uvn.as<int32_t>(), piv[c].off.as<int64_t>(),
+                                           piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 1, sw, s));
+            RC_TRY(mimc3_negate_uv_dev(ctx, sw, N, s));      // :289-293
+        }
+    }
+    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+
+    // ---- postprocess (:353)
+    RC_TRY(mimc3_postprocess_dev(ctx, d_dp.as<float>(), 32, xyuvav, d_xy.as<double>(), dimx, dimy, dt, res->mpp, res->meter_per_spacing,
+                                 p->radius_neighbor_dpf1, p->radius_neighbor_ps, p->qm_max_sweeps > 0 ? p->qm_max_sweeps : 101,
+                                 d_out5.as<float>(), s));
+    HIP_TRY(hipMemcpyAsync(vx, d_out5.as<float>(), 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(vy, d_out5.as<float>() + n, 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ex, d_out5.as<float>() + 2 * n, 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ey, d_out5.as<float>() + 3 * n, 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(qual, d_out5.as<float>() + 4 * n, 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+
+    // ---- sub-integer CP offset = grid mean, removed; px -> m/yr (:356-402), f32 in the reference's order
+    float sdu = 0.0f, sdv = 0.0f;
+    int32_t num = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!std::isnan(vx[i]) && !std::isnan(vy[i])) { sdu += vx[i]; sdv += vy[i]; num++; }
+    const float du_cp = sdu / (float)num, dv_cp = sdv / (float)num;
+    res->cp_subint[0] = du_cp; res->cp_subint[1] = dv_cp;
+    const float factor = res->mpp / dt * 365;
+    for (size_t i = 0; i < n; i++) {
+        const float a = vx[i] - du_cp, b = vy[i] - dv_cp;
+        vx[i] = a * factor;
+        vy[i] = -b * factor;
+        ex[i] = (float)(std::sqrt((double)ex[i]) * (double)factor);
+        ey[i] = (float)(std::sqrt((double)ey[i]) * (double)factor);
+    }
+    return 0;
+}

@@ -95,3 +95,22 @@ def test_filtered_passes_end_to_end(api, oracle, name):
         ctx.filter_images(None)                            # back to the raw pair
         assert_bits_equal(ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw), raw, "raw again")
         assert ctx.last_path() == "u8_exact"
+
+
+def test_three_filters_reuse_the_output_planes(api, oracle):
+    """MIMC_main.c:302-307: i0c/i1c are created once; each filter inherits the border the previous one left"""
+    c = synth.make_small(seed=33, shift=(1, 2), angle_deg=-60.0, ocw=7, null_frac=0.05)
+    H, W = c.i0.shape
+    o0 = np.zeros_like(c.i0); o1 = np.zeros_like(c.i1)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        for name in ("ddx", "ddy", "laplacian"):
+            o0 = oracle.float_conv2(c.i0, KERNELS[name], o0)
+            o1 = oracle.float_conv2(c.i1, KERNELS[name], o1)
+            ctx.filter_images(KERNELS[name])
+            g0, g1 = ctx.get_images(H, W)
+            assert_bits_equal(g0, o0, name + " i0"); assert_bits_equal(g1, o1, name + " i1")
+        assert not np.array_equal(o0, oracle.float_conv2(c.i0, KERNELS["laplacian"]))     # the inherited border matters
+        ctx.set_images(c.i0, c.i1)                          # a new pair starts from zero planes again
+        ctx.filter_images(KERNELS["laplacian"])
+        assert_bits_equal(ctx.get_images(H, W)[0], oracle.float_conv2(c.i0, KERNELS["laplacian"]), "fresh")
