@@ -1,0 +1,192 @@
+// MIMC3_hip -- the reference program's command line over libmimc3_hip.so (MI355X).
+//
+//     MIMC3_hip <i0.tif> <i1.tif> <xyuvav.GMA> <outdir>
+//
+// Same arguments, same files in <outdir>, same exit behaviour as the reference's main() (MIMC_main.c:43-528):
+//   * image paths must contain a '/' and their basename must start with YYYYMMDDhhmmss (getTimeStampStr,
+//     MIMC_misc.c:133-153); dt = difference of the two timestamps in days (get_datenum / get_dt, :27-131)
+//   * <outdir>/vmap_<t0>_<t1>.tar already there -> "vmap already exists. Skipping", exit -1 (:122-130)
+//   * not enough control points -> an empty vmap_<t0>_<t1>.tar is created, exit -1 (:246-252)
+//   * outputs: vmap_<t0>_<t1>_{x,y}.GMA (f64 1 x dim), _{vx,vy,ex,ey,qual}.GMA (f32 dimy x dimx), _flagcp.GMA (u8),
+//     _meta.txt (7 key=value lines) (:404-447)
+// Everything between "inputs loaded" and "save the output" is mimc3_vmap() on the GPU; there is no CPU path.
+// Environment: MIMC3_HIP_DEVICE (default 0), MIMC3_CP_SEED (pin the control-point shuffle; default time(NULL) like
+// the reference).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <unistd.h>
+#include <tiffio.h>
+#include "../../../include/mimc3_hip.h"
+
+namespace {
+
+bool leap(int y) { return y % 4 == 0 && (y % 100 != 0 || y % 400 == 0); }          // MIMC_misc.c:9-25
+
+double datenum(const char *s)                                                       // MIMC_misc.c:27-119
+{
+    char buf[8];
+    auto field = [&](int at, int len) { std::memset(buf, 0, sizeof buf); std::memcpy(buf, s + at, len); return buf; };
+    const int y = atoi(field(0, 4));
+    const int m = atoi(field(4, 2));
+    const int d = atoi(field(6, 2));
+    const double H = atof(field(8, 2));
+    const double M = atof(field(10, 2));
+    const double S = atof(field(12, 2));
+    double off = 0.0;
+    for (int k = 0; k < y; k++) off += leap(k) ? 366.0 : 365.0;
+    static const int acc_n[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
+    static const int acc_l[12] = {0, 31, 60, 91, 121, 152, 182, 213, 244, 274, 305, 335};
+    const int *acc = leap(y) ? acc_l : acc_n;
+    off += (double)acc[m - 1] + (double)d + H / 24.0 + M / 1440.0 + S / 86400.0;
+    return off;
+}
+
+bool timestamp_of(const char *path, char out[15])                                   // MIMC_misc.c:133-153
+{
+    const char *slash = std::strrchr(path, '/');
+    if (!slash || std::strlen(slash + 1) < 14) return false;      // the reference reads garbage here; this refuses
+    std::memcpy(out, slash + 1, 14);
+    out[14] = '\0';
+    for (int i = 0; i < 14; i++)
+        if (out[i] < '0' || out[i] > '9') return false;
+    return true;
+}
+
+// GMA_float_load_tiff (GMA.c:246-316): scanline reader, bytes per pixel = scanline size / width, 1 -> u8, else u16
+bool load_tiff(const char *path, std::vector<float> &img, int32_t &H, int32_t &W)
+{
+    TIFF *tif = TIFFOpen(path, "r");
+    if (!tif) return false;
+    uint32_t h = 0, w = 0;
+    TIFFGetField(tif, TIFFTAG_IMAGELENGTH, &h);
+    TIFFGetField(tif, TIFFTAG_IMAGEWIDTH, &w);
+    const tsize_t scan = TIFFScanlineSize(tif);
+    if (h == 0 || w == 0 || scan <= 0) { TIFFClose(tif); return false; }
+    const int bpp = (int)((uint32_t)scan / w);
+    std::vector<unsigned char> buf((size_t)scan);
+    img.resize((size_t)h * w);
+    for (uint32_t r = 0; r < h; r++) {
+        if (TIFFReadScanline(tif, buf.data(), r, 0) < 0) { TIFFClose(tif); return false; }
+        float *o = img.data() + (size_t)r * w;
+        if (bpp == 1) for (uint32_t c = 0; c < w; c++) o[c] = (float)buf[c];
+        else { const uint16_t *p16 = reinterpret_cast<const uint16_t *>(buf.data()); for (uint32_t c = 0; c < w; c++) o[c] = (float)p16[c]; }
+    }
+    TIFFClose(tif);
+    H = (int32_t)h; W = (int32_t)w;
+    printf("Loading TIFF - row=%d, col=%d, bytes per pixel=%d\n", H, (int)scan, bpp);
+    return true;
+}
+
+// .GMA container (GMA.c:168-244, :319-424): int32 rows, int32 cols, row-major payload
+bool load_gma_double(const char *path, std::vector<double> &v, int32_t &rows, int32_t &cols)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    bool ok = fread(&rows, 4, 1, f) == 1 && fread(&cols, 4, 1, f) == 1 && rows > 0 && cols > 0;
+    if (ok) { v.resize((size_t)rows * cols); ok = fread(v.data(), 8, v.size(), f) == v.size(); }
+    fclose(f);
+    return ok;
+}
+template <class T> bool save_gma(const std::string &path, const T *p, int32_t rows, int32_t cols)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(&rows, 4, 1, f) == 1 && fwrite(&cols, 4, 1, f) == 1 && fwrite(p, sizeof(T), (size_t)rows * cols, f) == (size_t)rows * cols;
+    return fclose(f) == 0 && ok;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+    const char ver[] = "3.0.7";        // the reference version whose outputs this build reproduces (meta key MIMC_version)
+    printf("\n\nMIMC version %s -- MI355X build (%s)\n\n", ver, mimc3_version());
+    if (argc != 5) {
+        fprintf(stderr, "usage: %s <i0.tif> <i1.tif> <xyuvav.GMA> <outdir>\n", argv[0]);
+        return 2;
+    }
+    char t0[15], t1[15];
+    if (!timestamp_of(argv[1], t0) || !timestamp_of(argv[2], t1)) {
+        fprintf(stderr, "image paths must contain a '/' and the file names must start with YYYYMMDDhhmmss\n");
+        return 2;
+    }
+    const std::string base = std::string(argv[4]) + "/vmap_" + t0 + "_" + t1;
+    const std::string f_tar = base + ".tar";
+    const float dt = (float)(datenum(t1) - datenum(t0));                                // get_dt, MIMC_misc.c:121-131
+    printf("dt=%f days\n\nEarlier image: %s\nLatter image: %s\nxyuvav matrix: %s\n", dt, argv[1], argv[2], argv[3]);
+    if (access(f_tar.c_str(), F_OK) == 0) {                                             // :122-130
+        printf("vmap already exists. Skipping\n");
+        return -1;
+    }
+
+    // ---- parameters and kernels (:134-194)
+    static const float k_dx[3] = {-1, 0, 1}, k_dy[3] = {-1, 0, 1};
+    static const float k_lap[9] = {-1.0 / 8, -1.0 / 8, -1.0 / 8, -1.0 / 8, 1.0, -1.0 / 8, -1.0 / 8, -1.0 / 8, -1.0 / 8};
+    mimc3_vmap_params p{};
+    p.vec_ocw[0] = 7; p.vec_ocw[1] = 15; p.vec_ocw[2] = 30; p.vec_ocw[3] = 40;
+    p.aw_cre = 10.0f; p.aw_sf = 1.8f;
+    p.radius_neighbor_dpf1 = 1000 / 300; p.radius_neighbor_ps = 5.0f;
+    p.num_cp_max = 500; p.num_cp_min = 50; p.ratio_cp = 0.03f; p.thres_spd_cp = 10;
+    p.kernel[0] = k_dx; p.kdim[0][0] = 1; p.kdim[0][1] = 3;
+    p.kernel[1] = k_dy; p.kdim[1][0] = 3; p.kdim[1][1] = 1;
+    p.kernel[2] = k_lap; p.kdim[2][0] = 3; p.kdim[2][1] = 3;
+    const char *seed = getenv("MIMC3_CP_SEED");
+    p.cp_seed = seed ? atoll(seed) : -1;
+    p.qm_max_sweeps = 101;
+
+    // ---- inputs (:200-230)
+    std::vector<double> xy;
+    int32_t N = 0, ncol = 0;
+    if (!load_gma_double(argv[3], xy, N, ncol) || ncol != 6) { fprintf(stderr, "cannot read %s as an [N][6] float64 .GMA\n", argv[3]); return 2; }
+    std::vector<float> i0, i1;
+    int32_t H = 0, W = 0, H1 = 0, W1 = 0;
+    if (!load_tiff(argv[1], i0, H, W) || !load_tiff(argv[2], i1, H1, W1)) { fprintf(stderr, "cannot read the TIFF images\n"); return 2; }
+    if (H != H1 || W != W1) { fprintf(stderr, "the two images differ in size\n"); return 2; }
+
+    const char *dev = getenv("MIMC3_HIP_DEVICE");
+    mimc3_ctx *ctx = nullptr;
+    if (mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx)) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
+    if (mimc3_ctx_set_images(ctx, i0.data(), i1.data(), H, W)) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
+
+    std::vector<float> vx(N), vy(N), ex(N), ey(N), qual(N);
+    std::vector<uint8_t> flag(N);
+    mimc3_vmap_result r{};
+    if (mimc3_vmap(ctx, xy.data(), N, dt, &p, vx.data(), vy.data(), ex.data(), ey.data(), qual.data(), flag.data(), &r)) {
+        fprintf(stderr, "%s\n", mimc3_last_error());
+        mimc3_ctx_destroy(ctx);
+        return 3;
+    }
+    mimc3_ctx_destroy(ctx);
+    printf("MPP=%f, grid spacing=%f, meter per spacing=%fm\nDimension of the vmap: %d by %d (mapy / mapx)\n", r.mpp, r.spacing_grid,
+           r.meter_per_spacing, r.dimy, r.dimx);
+    if (r.cp_status < 0) {                                                              // :246-252
+        printf("Generating dummy vmap file.\n");
+        FILE *f = fopen(f_tar.c_str(), "ab");
+        if (f) fclose(f);
+        return -1;
+    }
+    printf("Measured offset: [%d, %d] pixels (i1-i0)\n", r.offset_cp[0], r.offset_cp[1]);
+
+    // ---- outputs (:404-447)
+    std::vector<double> gx(r.dimx), gy(r.dimy);
+    for (int32_t c = 0; c < r.dimx; c++) gx[c] = xy[6 * (size_t)c];
+    for (int32_t c = 0; c < r.dimy; c++) gy[c] = xy[6 * (size_t)c * r.dimx + 1];
+    printf("Saving the output\n");
+    bool ok = save_gma(base + "_x.GMA", gx.data(), 1, r.dimx) && save_gma(base + "_y.GMA", gy.data(), 1, r.dimy) &&
+              save_gma(base + "_vx.GMA", vx.data(), r.dimy, r.dimx) && save_gma(base + "_vy.GMA", vy.data(), r.dimy, r.dimx) &&
+              save_gma(base + "_ex.GMA", ex.data(), r.dimy, r.dimx) && save_gma(base + "_ey.GMA", ey.data(), r.dimy, r.dimx) &&
+              save_gma(base + "_qual.GMA", qual.data(), r.dimy, r.dimx) && save_gma(base + "_flagcp.GMA", flag.data(), r.dimy, r.dimx);
+    FILE *fm = fopen((base + "_meta.txt").c_str(), "w");
+    if (fm) {
+        fprintf(fm, "MIMC_version=%s\nname_i0=%s\nname_i1=%s\ncp_offset_int_u=%d\ncp_offset_int_v=%d\ncp_offset_subint_u=%f\ncp_offset_subint_v=%f\n",
+                ver, argv[1], argv[2], r.offset_cp[0], r.offset_cp[1], r.cp_subint[0], r.cp_subint[1]);
+        ok = fclose(fm) == 0 && ok;
+    } else ok = false;
+    if (!ok) { fprintf(stderr, "could not write the outputs under %s\n", argv[4]); return 4; }
+    printf("Processing completed\n");
+    return 0;
+}

@@ -136,6 +136,33 @@ def main():
         print(f"cp_small seed {sd}: rc={rc} offset={off.tolist()} cps={int(flag.sum())}")
     np.savez_compressed(os.path.join(OUT, "cp_small.npz"), **d)
 
+    # N3: the whole reference PROGRAM (oracle/_ref/MIMC3_ref = unmodified main() + zero-filling malloc + pinned shuffle
+    # seed) on a small TIFF pair: its eight .GMA outputs and meta.txt
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fileio
+    prog = os.path.join(ROOT, "oracle", "_ref", "MIMC3_ref")
+    h, w, dimx, dimy = 400, 420, 14, 12
+    i0, i1 = synth.make_pair(h, w, (2, -1), seed=91, null_frac=0.02, noise_dn=2)
+    xy = synth.make_grid(dimx, dimy, 70, 70, (w - 140) // dimx, (h - 140) // dimy, 900.0, angle_deg=30.0)
+    rng = np.random.default_rng(91)
+    slow = rng.random(dimx * dimy) < 0.6
+    xy[slow, 4] = rng.uniform(-5, 5, slow.sum()); xy[slow, 5] = rng.uniform(-5, 5, slow.sum())
+    t0, t1, seed = "20200101103000", "20200117103000", 7
+    with tempfile.TemporaryDirectory() as d:
+        fileio.write_tiff(f"{d}/{t0}_i0.tif", i0.astype(np.uint8)); fileio.write_tiff(f"{d}/{t1}_i1.tif", i1.astype(np.uint8))
+        fileio.write_gma(f"{d}/xyuvav.GMA", xy)
+        os.makedirs(f"{d}/out")
+        subprocess.run([prog, f"{d}/{t0}_i0.tif", f"{d}/{t1}_i1.tif", f"{d}/xyuvav.GMA", f"{d}/out"], check=True,
+                       env=dict(os.environ, MIMC3_REF_SEED=str(seed)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = fileio.read_vmap(f"{d}/out", t0, t1)
+    meta = {k: v for k, v in r.pop("meta").items() if not k.startswith("name_")}
+    np.savez_compressed(os.path.join(OUT, "vmap_small.npz"), i0=i0.astype(np.uint8), i1=i1.astype(np.uint8), xyuvav=xy,
+                        t0=t0, t1=t1, seed=np.int64(seed), meta_keys=np.array(list(meta)), meta_vals=np.array(list(meta.values())),
+                        **{"out_" + k: v for k, v in r.items()})
+    print("vmap_small:", meta, "finite vx", float(np.isfinite(r["vx"]).mean()))
+
 
 if __name__ == "__main__":
     main()
