@@ -28,31 +28,43 @@ __device__ __forceinline__ float value_of(uint32_t k)
 
 __global__ __launch_bounds__(256) void conv2_init(uint32_t *minkey) { *minkey = key_of(1e+37f); }   // :2554
 
+// (int32_t)(p + 0.5) == 0 (:2545: f32 + f64 0.5, truncation) <=> -1.5 < p < 0.5; NaN and huge values are "not null"
+__device__ __forceinline__ bool null_dn(float p) { return p > -1.5f && p < 0.5f; }
+
 __global__ __launch_bounds__(256) void conv2_apply(Conv2Args a)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
     const int ox = a.kw / 2, oy = a.kh / 2;
-    float v = __builtin_nanf("");
-    if (c < a.W) {
-        const size_t idx = (size_t)r * a.W + c;
-        if (r >= oy && r < a.H - oy && c >= ox && c < a.W - ox) {
-            float s = 0.0f;
-            for (int i = 0; i < a.kh; i++)
-                for (int j = 0; j < a.kw; j++) {
-                    const float p = a.in[(size_t)(r + i - oy) * a.W + c + j - ox];
-                    const float dn = ((int32_t)((double)p + 0.5) != 0) ? p : __builtin_nanf("");      // :2545
-                    s += dn * a.k[i * a.kw + j];
-                }
-            a.out[idx] = s;
-            v = s;
-        } else v = a.out[idx];                                                // border: whatever the buffer holds
+    uint32_t key = 0xFFFFFFFFu;
+    // a block walks down its 256-column strip: one atomic per block at the end (same-address atomics serialise in L2)
+    for (int r = blockIdx.y; r < a.H; r += gridDim.y) {
+        float v = __builtin_nanf("");
+        if (c < a.W) {
+            const size_t idx = (size_t)r * a.W + c;
+            if (r >= oy && r < a.H - oy && c >= ox && c < a.W - ox) {
+                float s = 0.0f;
+                for (int i = 0; i < a.kh; i++)
+                    for (int j = 0; j < a.kw; j++) {
+                        const float p = a.in[(size_t)(r + i - oy) * a.W + c + j - ox];
+                        const float dn = null_dn(p) ? __builtin_nanf("") : p;
+                        s += dn * a.k[i * a.kw + j];
+                    }
+                a.out[idx] = s;
+                v = s;
+            } else v = a.out[idx];                                            // border: whatever the buffer holds
+        }
+        // minimum of the non-NaN values (`out < dn_min` is false for NaN, :2559)
+        if (v == v) key = min(key, key_of(v));
     }
-    // minimum of the non-NaN values (`out < dn_min` is false for NaN, :2559)
-    uint32_t key = (v == v) ? key_of(v) : 0xFFFFFFFFu;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, off));
-    if ((threadIdx.x & 63) == 0 && key != 0xFFFFFFFFu) atomicMin(a.minkey, key);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        key = min(min(part[0], part[1]), min(part[2], part[3]));
+        if (key != 0xFFFFFFFFu) atomicMin(a.minkey, key);
+    }
 }
 
 __global__ __launch_bounds__(256) void conv2_shift(Conv2Args a)
@@ -72,8 +84,9 @@ __global__ __launch_bounds__(256) void conv2_shift(Conv2Args a)
 hipError_t launch_conv2(const Conv2Args &a, hipStream_t stream)
 {
     const dim3 grid((a.W + 255) / 256, a.H), block(256);
+    const dim3 grid_apply((a.W + 255) / 256, a.H < 256 ? a.H : 256);
     hipLaunchKernelGGL(conv2_init, dim3(1), dim3(1), 0, stream, a.minkey);
-    hipLaunchKernelGGL(conv2_apply, grid, block, 0, stream, a);
+    hipLaunchKernelGGL(conv2_apply, grid_apply, block, 0, stream, a);
     hipLaunchKernelGGL(conv2_shift, grid, block, 0, stream, a);
     return hipGetLastError();
 }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void cp_conv_min(const float *__restrict__ img
         for (int i = 0; i < kk.kh; i++)
             for (int j = 0; j < kk.kw; j++) {
                 const float p = img[(size_t)(v - h1 + r + i - oy) * W + u - h1 + c + j - ox];
-                const float dn = ((int32_t)((double)p + 0.5) != 0) ? p : __builtin_nanf("");      // :2545
+                const float dn = (p > -1.5f && p < 0.5f) ? __builtin_nanf("") : p;      // :2545: (int32_t)(p + 0.5) == 0
                 s += dn * kk.k[i * kk.kw + j];
             }
         plane[q] = s;

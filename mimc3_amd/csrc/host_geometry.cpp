@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <thread>
+#include <vector>
 #include "../../include/mimc3_hip.h"
 #include "host_util.h"
 
@@ -70,13 +72,28 @@ extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, flo
 {
     if (!xyuvav || !piv_off || !total || N <= 0 || ocw < 1 || H <= 0 || W <= 0)
         return mimc3::fail(MIMC3_EINVAL, "mimc3_get_uv_pivot: bad argument");
+    // points are independent: both passes (count, fill) run on a few host threads; the prefix sum stays serial
+    const auto run = [&](auto &&body) {
+        unsigned nt = N >= 20000 ? std::thread::hardware_concurrency() : 1;
+        nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+        if (nt == 1) { body(0, N); return; }
+        std::vector<std::thread> th;
+        const int32_t step = (N + (int32_t)nt - 1) / (int32_t)nt;
+        for (int32_t b = 0; b < N; b += step) th.emplace_back(body, b, b + step < N ? b + step : N);
+        for (auto &t : th) t.join();
+    };
+    run([&](int32_t b, int32_t e) {
+        for (int32_t g = b; g < e; ++g) {
+            const double *r = xyuvav + 6 * (size_t)g;
+            const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
+            piv_off[g + 1] = c.count(r[2], r[3], ocw, H, W);
+        }
+    });
     int64_t tot = 0;
     bool empty = false;
     piv_off[0] = 0;
     for (int32_t g = 0; g < N; ++g) {
-        const double *r = xyuvav + 6 * (size_t)g;
-        const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
-        const int32_t n = c.count(r[2], r[3], ocw, H, W);
+        const int64_t n = piv_off[g + 1];
         if (n <= 0) empty = true;
         tot += n > 0 ? n : 0;
         piv_off[g + 1] = tot;
@@ -85,11 +102,13 @@ extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, flo
     if (empty) return mimc3::fail(MIMC3_EBOUNDS, "mimc3_get_uv_pivot: a grid point has zero pivots (too close to the image edge)");
     if (!piv_uv) return 0;
     if (cap < tot) return mimc3::fail(MIMC3_ECAP, "mimc3_get_uv_pivot: pivot capacity too small");
-    for (int32_t g = 0; g < N; ++g) {
-        const double *r = xyuvav + 6 * (size_t)g;
-        const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
-        c.fill((int32_t)(piv_off[g + 1] - piv_off[g]), piv_uv + 2 * piv_off[g]);
-    }
+    run([&](int32_t b, int32_t e) {
+        for (int32_t g = b; g < e; ++g) {
+            const double *r = xyuvav + 6 * (size_t)g;
+            const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
+            c.fill((int32_t)(piv_off[g + 1] - piv_off[g]), piv_uv + 2 * piv_off[g]);
+        }
+    });
     return 0;
 }
 

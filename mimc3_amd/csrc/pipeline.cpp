@@ -14,6 +14,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "../../include/mimc3_hip.h"
 #include "host_util.h"
 
@@ -24,6 +27,20 @@ struct Buf {
     ~Buf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// MIMC3_VMAP_TIMING=1: wall time of each stage of mimc3_vmap on stderr (the stream is drained at each mark)
+struct StageClock {
+    bool on = getenv("MIMC3_VMAP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what, hipStream_t s)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mimc3 vmap] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
 };
 
 int hip_fail(hipError_t e, const char *what)
@@ -129,11 +146,14 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     for (int k = 0; k < 3; k++) { cp.kernel[k] = p->kernel[k]; cp.kdim[k][0] = p->kdim[k][0]; cp.kdim[k][1] = p->kdim[k][1]; }
     std::memset(flag_cp, 0, (size_t)N);
     int32_t off[2] = {0, 0}, st = -1;
+    StageClock clk;
+    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
     RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
     RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
     res->cp_status = st;
     if (st < 0) return 0;                                   // the CLI touches vmap.tar and gives up (:248-252)
     res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1];
+    clk.mark("control-point offset", s);
 
     // ---- the reference refuses nothing, it reads out of bounds; this library refuses (see mimc3_match_ncc_dlc)
     int ocw_max = 0;
@@ -144,7 +164,6 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
             return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: grid point " + std::to_string(i) + " chip leaves the image");
     }
 
-    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
     const size_t n = (size_t)N;
     Buf d_xy, d_dp, d_out5;
     HIP_TRY(d_xy.alloc(48 * n));
@@ -172,9 +191,13 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
         HIP_TRY(hipStreamSynchronize(s));                   // the host vectors go out of scope
     }
 
+    clk.mark("pivots (host) + upload", s);
     // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
     for (int kk = -1; kk <= 2; kk++) {
-        if (kk >= 0) RC_TRY(mimc3_ctx_filter_images(ctx, p->kernel[kk], p->kdim[kk][0], p->kdim[kk][1]));
+        if (kk >= 0) {
+            RC_TRY(mimc3_ctx_filter_images(ctx, p->kernel[kk], p->kdim[kk][0], p->kdim[kk][1]));
+            clk.mark("filter + planes", s);
+        }
         for (int c = 0; c < 4; c++) {
             const int slot = (kk + 1) * 8 + c * 2;
             float *fw = d_dp.as<float>() + (size_t)slot * n * 3, *sw = fw + n * 3;
@@ -184,13 +207,16 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
                                            piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 1, sw, s));
             RC_TRY(mimc3_negate_uv_dev(ctx, sw, N, s));      // :289-293
         }
+        clk.mark("8 matcher passes", s);
     }
     RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+    clk.mark("back to the raw pair", s);
 
     // ---- postprocess (:353)
     RC_TRY(mimc3_postprocess_dev(ctx, d_dp.as<float>(), 32, xyuvav, d_xy.as<double>(), dimx, dimy, dt, res->mpp, res->meter_per_spacing,
                                  p->radius_neighbor_dpf1, p->radius_neighbor_ps, p->qm_max_sweeps > 0 ? p->qm_max_sweeps : 101,
                                  d_out5.as<float>(), s));
+    clk.mark("postprocess", s);
     HIP_TRY(hipMemcpyAsync(vx, d_out5.as<float>(), 4 * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(vy, d_out5.as<float>() + n, 4 * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ex, d_out5.as<float>() + 2 * n, 4 * n, hipMemcpyDeviceToHost, s));
@@ -213,5 +239,6 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
         ex[i] = (float)(std::sqrt((double)ex[i]) * (double)factor);
         ey[i] = (float)(std::sqrt((double)ey[i]) * (double)factor);
     }
+    clk.mark("download + unit conversion", s);
     return 0;
 }

@@ -61,6 +61,21 @@ def test_pivots_all_directions_vs_oracle(lib, oracle):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_pivots_large_grid_threaded_vs_oracle(lib, oracle):
+    """N >= 20000 takes the multi-threaded host path: same CSR as the serial oracle, every quadrant and speed"""
+    from mimc3_amd import api
+    n = 60000
+    rng = np.random.default_rng(3)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    spd = rng.uniform(0.0, 5000.0, n)
+    xy = np.zeros((n, 6))
+    xy[:, 2] = rng.uniform(45, 1955, n); xy[:, 3] = rng.uniform(45, 1755, n)       # some close to the edge: clipped corridors
+    xy[:, 4] = spd * np.cos(ang); xy[:, 5] = spd * np.sin(ang)
+    a = api.get_uv_pivot(xy, 16.0, 15.0, 40, 1800, 2000)
+    b = oracle.get_uv_pivot(xy, 16.0, 15.0, 40, 1800, 2000)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_zero_pivot_point_is_refused(lib):
     from mimc3_amd import api
     xy = np.array([[0, 0, 3.0, 3.0, 100.0, 100.0]])       # closer than ocw to the edge -> no pivot
