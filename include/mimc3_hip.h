@@ -233,6 +233,7 @@ int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const 
  *      convert_dpf_to_vxy_exy_qual, MIMC_module.h:64); size of the resident pair. --------------------------- */
 void *mimc3_ctx_stream(mimc3_ctx *ctx);
 int mimc3_negate_uv_dev(mimc3_ctx *ctx, float *d_out, int32_t N, void *stream);
+int mimc3_negate_pivots_dev(mimc3_ctx *ctx, const int32_t *d_piv_uv, int32_t *d_out /*[count][2]*/, int64_t count, void *stream); /* :272-279 */
 int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *ctx, const int32_t *d_dpf, const float *d_mvn, int32_t N, int32_t Kmax,
                                 float *d_out5, void *stream);
 int mimc3_ctx_image_size(mimc3_ctx *ctx, int32_t *H, int32_t *W);

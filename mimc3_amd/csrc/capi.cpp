@@ -900,6 +900,15 @@ extern "C" int mimc3_negate_uv_dev(mimc3_ctx *c, float *d_out, int32_t N, void *
     return 0;
 }
 
+extern "C" int mimc3_negate_pivots_dev(mimc3_ctx *c, const int32_t *d_piv_uv, int32_t *d_out, int64_t count, void *stream)
+{
+    if (!c || !d_piv_uv || !d_out || count <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_negate_pivots_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = mimc3::launch_negate_i32(d_piv_uv, d_out, 2 * count, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return mimc3::hip_fail(e, "negate kernel launch");
+    return 0;
+}
+
 extern "C" int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *c, const int32_t *d_dpf, const float *d_mvn, int32_t N, int32_t Kmax,
                                            float *d_out5, void *stream)
 {

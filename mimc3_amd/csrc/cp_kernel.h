@@ -20,4 +20,7 @@ hipError_t launch_cp_shift_copy(const float *tmp, const float *mn, int32_t n, in
 // (du, dv) -> (-du, -dv) on an [n][3] matcher output (swapped pass, :376-377)
 hipError_t launch_negate_uv(float *out, int32_t n, hipStream_t stream);
 
+// out[i] = -in[i]: the pivots of a swapped pass (MIMC_main.c:272-279)
+hipError_t launch_negate_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t stream);
+
 }  // namespace mimc3

@@ -106,7 +106,20 @@ __global__ __launch_bounds__(256) void negate_uv(float *out, int32_t n)
     out[3 * (size_t)i + 1] = -out[3 * (size_t)i + 1];
 }
 
+__global__ __launch_bounds__(256) void negate_i32(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -in[i];
+}
+
 }  // namespace
+
+hipError_t launch_negate_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(negate_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_cp_count_invalid(const float *img, int32_t H, int32_t W, const int32_t *uv, int32_t n, int32_t ocw, int32_t *counts,
                                    hipStream_t stream)

@@ -171,24 +171,33 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     HIP_TRY(d_out5.alloc(20 * n));
     HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
 
-    // ---- pivots per chip size (:264, :316), forward and negated (:272-279), resident for all four image variants
-    struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; };
+    // ---- pivots per chip size (:264, :316), forward and negated (:272-279), resident for all four image variants.
+    //      Host geometry (libm-exact, threaded) into ONE pinned staging buffer; the negated copy is made on the device.
+    struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; int64_t total = 0; };
     Piv piv[4];
-    for (int c = 0; c < 4; c++) {
-        std::vector<int64_t> po(n + 1);
-        int64_t total = 0;
-        RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po.data(), nullptr, 0, &total));
-        std::vector<int32_t> pu(2 * (size_t)total), pn(2 * (size_t)total);
-        RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po.data(), pu.data(), total, &total));
-        RC_TRY(mimc3_pivot_extent(pu.data(), po.data(), N, &piv[c].mn, &piv[c].mu, &piv[c].mv));
-        for (size_t i = 0; i < pu.size(); i++) pn[i] = -pu[i];
-        HIP_TRY(piv[c].uv.alloc(4 * pu.size()));
-        HIP_TRY(piv[c].uvn.alloc(4 * pn.size()));
-        HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
-        HIP_TRY(hipMemcpyAsync(piv[c].uv.p, pu.data(), 4 * pu.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(piv[c].uvn.p, pn.data(), 4 * pn.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(piv[c].off.p, po.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));                   // the host vectors go out of scope
+    {
+        std::vector<int64_t> po[4];
+        int64_t cap = 0;
+        for (int c = 0; c < 4; c++) {
+            po[c].resize(n + 1);
+            RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po[c].data(), nullptr, 0, &piv[c].total));
+            cap = piv[c].total > cap ? piv[c].total : cap;
+        }
+        struct Pinned { void *p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } stage;
+        HIP_TRY(hipHostMalloc(&stage.p, 8 * (size_t)cap, hipHostMallocDefault));
+        int32_t *pu = static_cast<int32_t *>(stage.p);
+        for (int c = 0; c < 4; c++) {
+            int64_t total = 0;
+            RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po[c].data(), pu, cap, &total));
+            RC_TRY(mimc3_pivot_extent(pu, po[c].data(), N, &piv[c].mn, &piv[c].mu, &piv[c].mv));
+            HIP_TRY(piv[c].uv.alloc(8 * (size_t)total));
+            HIP_TRY(piv[c].uvn.alloc(8 * (size_t)total));
+            HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
+            HIP_TRY(hipMemcpyAsync(piv[c].uv.p, pu, 8 * (size_t)total, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(piv[c].off.p, po[c].data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+            RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv.as<int32_t>(), piv[c].uvn.as<int32_t>(), total, s));
+            HIP_TRY(hipStreamSynchronize(s));               // the staging buffer is refilled for the next chip size
+        }
     }
 
     clk.mark("pivots (host) + upload", s);
