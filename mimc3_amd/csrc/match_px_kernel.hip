@@ -104,11 +104,15 @@ struct PxU8 {
     __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return nbad(v, keep, thr); }
     __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float) { return a; }     // nulls are already 0
     __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a) { sx = dot4(a, 0x01010101u, sx); sxx = dot4(a, a, sxx); }
-    template <int MODE>
+    template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t pad01, uint32_t padff, bool static_pad, uint32_t bw, float)
     {
         // byte mask of the chip group: 0xFF where the chip pixel is valid (null pixels and the pad bytes of the
-        // last group are 0 in `a`), derived on the fly -- keeping it in registers would cost a second chip image
+        // last group are 0 in `a`), derived on the fly -- keeping it in registers would cost a second chip image.
+        // The chip is loop-invariant, so the compiler WOULD hoist every mask out of the evaluation loops (80+
+        // VGPRs for the big chips, i.e. spills): the empty asm makes `a` opaque per task (OPQ, big chips only --
+        // the small chips have the registers and are faster with the hoisted masks).
+        if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a));
         const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
         if (MODE == M_FAST) {
             const uint32_t m01 = static_pad ? pad01 : (mf & 0x01010101u);
@@ -182,9 +186,10 @@ struct PxU16 {
     {
         sx = dot2(a, 0x00010001u, (uint32_t)sx); sxx = dot2(a, a, (uint32_t)sxx);
     }
-    template <int MODE>
+    template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t, uint32_t padff, bool static_pad, uint32_t bw, float)
     {
+        if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a)); // see PxU8::task: keeps the masks out of registers
         const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ffff_from8000(nz8000(a));
         if (MODE == M_FAST || MODE == M_CHIPNULL) {
             acc.sy = dot2(mf & 0x00010001u, bw, (uint32_t)acc.sy);
@@ -237,7 +242,7 @@ struct PxF32 {
         const float f = __uint_as_float(a);
         sx += (double)f; sxx += (double)(f * f);
     }
-    template <int MODE>
+    template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t, uint32_t, bool, uint32_t bu, float thr)
     {
         const float a = __uint_as_float(au), b = __uint_as_float(bu);   // a is 0.0 for excluded chip pixels and unused slots
@@ -293,6 +298,7 @@ struct PxCfg {
     static constexpr uint32_t LASTFF = P::lowmask_c(LASTN);
     static constexpr uint32_t LAST01 = LASTFF & 0x01010101u;
     static constexpr int CPR = 64 / LPC;                     // cells per evaluation round
+    static constexpr bool OPQ = LPC_ >= 64;                  // big chips: keep chip-derived masks out of registers (see PxU8::task)
 };
 
 struct U8Point {
@@ -327,14 +333,14 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
             const uint32_t bw = (P::G > 1) ? alignb(w[j + (P::G > 1 ? 1 : 0)], w[j], s) : w[j];
             const uint32_t p01 = (j == C::GPR - 1) ? C::LAST01 : 0x01010101u;
             const uint32_t pff = (j == C::GPR - 1) ? C::LASTFF : 0xffffffffu;
-            P::template task<MODE>(acc, A[i][j], p01, pff, true, bw, pt.thr);
+            P::template task<MODE, C::OPQ>(acc, A[i][j], p01, pff, true, bw, pt.thr);
         }
     }
 #pragma unroll
     for (int k = 0; k < C::TT; k++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + toff[k]);
         const uint32_t bw = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], s) : rp[0];
-        P::template task<MODE>(acc, AT[k], 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from AT[k] itself
+        P::template task<MODE, C::OPQ>(acc, AT[k], 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from AT[k] itself
     }
     acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE == M_GENERAL) {
@@ -1060,8 +1066,8 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU16, 16, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
