@@ -1066,9 +1066,9 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU16, 16, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }
