@@ -76,6 +76,8 @@ struct mimc3_ctx {
     DevBuf filt0, filt1, conv_io;       // pre-filtered pair (mimc3_ctx_filter_images), conv2 staging
     DevBuf cp_buf;                      // control-point stage: one arena carved per call
     bool filt_live = false;             // filt0/filt1 hold the output planes of an earlier filter pass on this pair
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // CP stage: its 16 small matcher launches per segment overlap on 4 streams
+    hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -123,6 +125,8 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
     c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
+    for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
+    for (auto &ev : c->ev_side) if (ev) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -703,6 +707,8 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int H = c->H, W = c->W;
+    for (auto &st : c->side) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &ev : c->ev_side) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     // ---- candidates: slow a-priori points (:64-78) whose ocw[2] chip of i0 is mostly valid (:81-112)
     int32_t num_cp;
@@ -841,10 +847,16 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                 HIP_TRY(mimc3::launch_cp_shift_copy(d_t0, d_mn0, n, ocw_chip, d_a0, s));
                 HIP_TRY(mimc3::launch_cp_shift_copy(d_t1, d_mn1, n, ocw_chip, d_a1, s));
             }
+            // the four matches of this image variant (2 chip sizes x forward/swapped) are a few hundred workgroups each:
+            // they run side by side on four streams, forked from and joined back into the context's stream
+            HIP_TRY(hipEventRecord(c->ev_side[3], s));
             for (int c3 = 1; c3 < 3; c3++) {                                       // :330-384
                 const int ocw = p->vec_ocw[c3];
                 const int32_t slot = (c3 - 1) * 8 + (kk + 1) * 2;
                 for (int sw = 0; sw < 2; sw++) {
+                    const int lane_id = (c3 - 1) * 2 + sw;                         // 0..3; lane 0 = the context's own stream
+                    hipStream_t ms = lane_id == 0 ? s : c->side[lane_id - 1];
+                    if (lane_id) HIP_TRY(hipStreamWaitEvent(ms, c->ev_side[3], 0));
                     mimc3::MatchArgs a{};
                     a.i0 = d_a0; a.i1 = d_a1; a.H = n * cs; a.W = cs;
                     a.xyuvav = d_xy; a.N = n; a.off_u = 0; a.off_v = 0;
@@ -852,9 +864,13 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                     a.thr = min_dn_threshold();
                     a.out = d_dp + (size_t)(slot + sw) * n * 3;
                     const int reach = ocw_chip - ocw - 2;
-                    hipError_t e = mimc3::launch_match_f32(a, reach, reach, npiv, s);
+                    hipError_t e = mimc3::launch_match_f32(a, reach, reach, npiv, ms);
                     if (e != hipSuccess) return mimc3::hip_fail(e, "control-point match launch");
-                    if (sw) HIP_TRY(mimc3::launch_negate_uv(a.out, n, s));          // :376-377
+                    if (sw) HIP_TRY(mimc3::launch_negate_uv(a.out, n, ms));         // :376-377
+                    if (lane_id) {
+                        HIP_TRY(hipEventRecord(c->ev_side[lane_id - 1], ms));
+                        HIP_TRY(hipStreamWaitEvent(s, c->ev_side[lane_id - 1], 0)); // the next variant overwrites the atlas
+                    }
                 }
             }
         }

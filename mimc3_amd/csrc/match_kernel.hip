@@ -382,7 +382,7 @@ hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_n
     }
     // grid rounded up to a multiple of 8 so the XCD remap is a bijection on [0, 8*per)
     unsigned nb = (unsigned)((a.N + 7) & ~7);
-    if (a.point_list) nb = nb < 1024u ? nb : 1024u;      // list mode: small persistent grid
+    if (a.point_list) nb = nb < 256u ? nb : 256u;        // list mode: one persistent workgroup per CU (the list is usually empty)
     if (win_lds)
         hipLaunchKernelGGL(match_ncc_dlc_f32<true>, dim3(nb), dim3(kMatchThreads), bytes, stream, a);
     else
