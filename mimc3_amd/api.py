@@ -391,7 +391,7 @@ class Context:
         _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1, "f32": 2, "u16": 3}.get(mode, mode)), "set_path")
 
     def last_path(self):
-        return {0: "general_f32", 1: "u8_exact", 2: "f32_tiled", 3: "u16_scaled"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
+        return {0: "general_f32", 1: "u8_exact", 2: "f32_tiled", 3: "u16_scaled", 4: "u8_offset"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
 
     # -- timing -------------------------------------------------------------------------------
     def enable_timing(self, on=True):

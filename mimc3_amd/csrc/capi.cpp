@@ -59,6 +59,8 @@ struct mimc3_ctx {
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
+    DevBuf fail;                        // [0] count, [1..] points the offset-u8 kernel handed to the u16 kernel
+    bool u8o_ok = false;                // integer (shift 0) u16 planes whose local range mostly fits 8 bits: try PxU8o first
     DevBuf hpl0, hpl1;                  // zero-bordered u16 planes of scaled integers (q = value * 2^shift < 4096)
     bool u16_ok = false;                // the pair is scaled-integer (and not 8-bit): u16 planes are built
     bool hpl_valid = false;             // u16 planes hold the CURRENT pair
@@ -120,7 +122,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
-    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fpl0.release(); c->fpl1.release(); c->hpl0.release(); c->hpl1.release();
+    c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fail.release(); c->fpl0.release(); c->fpl1.release(); c->hpl0.release(); c->hpl1.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
@@ -158,6 +160,7 @@ static int prepare_u8(mimc3_ctx *c)
     c->u8_ok = (not_u8 == 0);
     c->u16_ok = false;
     c->hpl_valid = false;
+    c->u8o_ok = false;
     if (!c->u8_ok) {
         // not 8-bit: is the pair "scaled integer" (12-bit DN, or what GMA_float_conv2 makes of 8-bit images:
         // integers / multiples of 1/8)?  Then the exact u16 kernel applies.
@@ -180,6 +183,19 @@ static int prepare_u8(mimc3_ctx *c)
             HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, pad, s1, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->shift0 = s0; c->shift1 = s1; c->u16_ok = true; c->hpl_valid = true;
+            // 9-bit integers (gradients of 8-bit images): does the LOCAL range fit 8 bits almost everywhere?  Then the
+            // u8 kernels can run them through per-point offsets (PxU8o); the few points that do not fit go to PxU16.
+            c->u8o_ok = false;
+            if (s0 == 0 && s1 == 0 && !getenv("MIMC3_NO_U8O")) {
+                int t[4] = {0, 0, 0, 0};
+                HIP_TRY(c->flag.reserve(4 * sizeof(int)));
+                HIP_TRY(hipMemsetAsync(c->flag.p, 0, 4 * sizeof(int), c->stream));
+                HIP_TRY(mimc3::launch_range_tiles(static_cast<const unsigned short *>(c->hpl0.p), c->H, c->W, c->Wp, pad, static_cast<int *>(c->flag.p), c->stream));
+                HIP_TRY(mimc3::launch_range_tiles(static_cast<const unsigned short *>(c->hpl1.p), c->H, c->W, c->Wp, pad, static_cast<int *>(c->flag.p) + 2, c->stream));
+                HIP_TRY(hipMemcpyAsync(t, c->flag.p, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->u8o_ok = 2 * t[0] >= t[1] && 2 * t[2] >= t[3];
+            }
         }
     }
     return 0;
@@ -293,8 +309,23 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         } else if (want_u16) {
             u.p0 = static_cast<const unsigned char *>(c->hpl0.p); u.p1 = static_cast<const unsigned char *>(c->hpl1.p);
             u.scale0 = 1.0 / (double)(1 << c->shift0); u.scale1 = 1.0 / (double)(1 << c->shift1);
-            e = mimc3::launch_match_u16(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
-            c->last_path = 3;
+            if (c->u8o_ok && c->u16_ok && c->path_mode == 0) {
+                // u8 machinery through per-point offsets first; what does not fit is redone by the u16 kernel in list mode
+                HIP_TRY(c->fail.reserve(sizeof(int32_t) * ((size_t)N + 1)));
+                HIP_TRY(hipMemsetAsync(c->fail.p, 0, sizeof(int32_t), s));
+                u.fail_count = static_cast<int32_t *>(c->fail.p);
+                u.fail_list = u.fail_count + 1;
+                e = mimc3::launch_match_u8o(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+                if (e == hipSuccess) {
+                    u.point_count = u.fail_count; u.point_list = u.fail_list;
+                    u.fail_count = nullptr; u.fail_list = nullptr;
+                    e = mimc3::launch_match_u16(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+                }
+                c->last_path = 4;
+            } else {
+                e = mimc3::launch_match_u16(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+                c->last_path = 3;
+            }
         } else {
             if (!c->fplanes_ok) {      // zero-bordered f32 copies of the pair, once per image pair
                 const size_t bytes = sizeof(float) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;

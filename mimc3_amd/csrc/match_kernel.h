@@ -44,6 +44,8 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t ocw, swap;
     float *out;
     int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
+    const int32_t *point_list, *point_count;   // list mode: workgroup b handles point_list[b], b < *point_count (nullptr = all N points)
+    int32_t *fail_list, *fail_count;           // PxU8o only: points whose chip or window does not fit a local 8-bit range
     // LDS carve, filled by the launcher
     int32_t lds_pw, lds_off_val, lds_off_ncc, lds_off_req, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
@@ -61,6 +63,10 @@ bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v);
 hipError_t launch_detect_scaled_int(const float *img, size_t n, int *d_flags, hipStream_t s);
 hipError_t launch_prep_u16(const float *img, int H, int W, unsigned short *plane, int Wp, int pad, int shift, hipStream_t s);
 hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
+// u16 planes of INTEGERS read through a per-point offset into the u8 kernels (points that do not fit go to fail_list)
+hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
+// fraction-of-tiles estimate for the above: out[0] += tiles whose non-null range fits 8 bits, out[1] += tiles with data
+hipError_t launch_range_tiles(const unsigned short *plane, int H, int W, int Wp, int pad, int *d_out2, hipStream_t s);
 // same kernel family on zero-bordered f32 planes (any f32 imagery; small chips only)
 hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp, int pad, hipStream_t s);
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v);

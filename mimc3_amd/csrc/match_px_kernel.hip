@@ -95,6 +95,7 @@ __device__ __forceinline__ double dpp_add_f64(double x, int ctrl_sel)
 // ---- pixel policy: 8-bit integral imagery, 4 pixels per dword, exact integer sums --------------------
 struct PxU8 {
     static constexpr int BPP = 1, G = 4, LOG2G = 2;
+    static constexpr bool SRC16 = false;
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -140,7 +141,7 @@ struct PxU8 {
     typedef uint32_t Store;                                    // how a reduced sum is parked in LDS
     __device__ static __forceinline__ Store bits(Sum v) { return v; }
     // NCC from exact integer sums (MIMC_module.c:734), f64, no contraction
-    __device__ static __forceinline__ float ncc(const Store *sp, double, double)
+    __device__ static __forceinline__ float ncc(const Store *sp, double, double, int, int)
     {
         const double dn = (double)sp[0], dsx = (double)sp[1], dsy = (double)sp[2];
         const double num = dn * (double)sp[5] - dsx * dsy;
@@ -175,6 +176,7 @@ __device__ __forceinline__ unsigned long long dpp_add_u64(unsigned long long x, 
 }
 struct PxU16 {
     static constexpr int BPP = 2, G = 2, LOG2G = 1;
+    static constexpr bool SRC16 = false;
     typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
@@ -216,7 +218,7 @@ struct PxU16 {
     }
     typedef unsigned long long Store;
     __device__ static __forceinline__ Store bits(Sum v) { return v; }
-    __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb)
+    __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb, int, int)
     {
         const double dn = (double)(uint32_t)sp[0];
         const double sx = (double)sp[1] * sa, sy = (double)sp[2] * sb;            // exact: powers of two
@@ -227,9 +229,51 @@ struct PxU16 {
     }
 };
 
+// ---- pixel policy: scaled-integer imagery whose LOCAL dynamic range fits 8 bits, read through a per-point offset.
+//      The gradient filters of 8-bit images give 9-bit integers (1..511) whose range inside one chip / one search
+//      window almost never exceeds 254: such a point is staged as q' = q - k (k = local minimum - 1, separately for
+//      chip and window, nulls stay 0) and runs on the u8 machinery (dot4, 4 px per dword).  The exact sums of the
+//      true values follow from the primed ones:  sx = sx' + ka n,  sxx = sxx' + 2 ka sx' + ka^2 n,
+//      sxy = sxy' + kb sx' + ka sy' + ka kb n  (n = pixels that take part), all in 64-bit integers, so the NCC is
+//      bit-identical to the u16 path's.  Points that do not fit are handed to the u16 kernel through fail_list. -------
+struct PxU8o : PxU8 {
+    static constexpr bool SRC16 = true;
+    __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb, int ka, int kb)
+    {
+        const long long n = sp[0], sx_ = sp[1], sy_ = sp[2], sxx_ = sp[3], syy_ = sp[4], sxy_ = sp[5];
+        const long long A = ka, B = kb;
+        const long long sxi = sx_ + A * n, syi = sy_ + B * n;
+        const long long sxxi = sxx_ + 2 * A * sx_ + A * A * n, syyi = syy_ + 2 * B * sy_ + B * B * n;
+        const long long sxyi = sxy_ + B * sx_ + A * sy_ + A * B * n;
+        const double dn = (double)n;
+        const double sx = (double)sxi * sa, sy = (double)syi * sb;                  // exact: powers of two (as PxU16::ncc)
+        const double sxx = (double)sxxi * (sa * sa), syy = (double)syyi * (sb * sb), sxy = (double)sxyi * (sa * sb);
+        const double num = dn * sxy - sx * sy;
+        const double den = sqrt((dn * sxx - sx * sx) * (dn * syy - sy * sy));
+        return (float)(num / den);
+    }
+    // four u16 pixels (two dwords) -> four u8 pixels q - k (0 stays 0); bytes are confined even when q - k is out of range
+    __device__ static __forceinline__ uint32_t pack(uint2 v, int k)
+    {
+        const uint32_t q0 = v.x & 0xffffu, q1 = v.x >> 16, q2 = v.y & 0xffffu, q3 = v.y >> 16;
+        const uint32_t b0 = q0 ? ((q0 - (uint32_t)k) & 0xffu) : 0u, b1 = q1 ? ((q1 - (uint32_t)k) & 0xffu) : 0u;
+        const uint32_t b2 = q2 ? ((q2 - (uint32_t)k) & 0xffu) : 0u, b3 = q3 ? ((q3 - (uint32_t)k) & 0xffu) : 0u;
+        return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    // min / max over the non-null pixels of four u16 pixels selected by the byte mask `keep`
+    __device__ static __forceinline__ void range4(uint2 v, uint32_t keep, int &mn, int &mx)
+    {
+        const uint32_t q[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (((keep >> (8 * i)) & 0xffu) && q[i]) { mn = min(mn, (int)q[i]); mx = max(mx, (int)q[i]); }
+    }
+};
+
 // ---- pixel policy: arbitrary f32 imagery, 1 pixel per dword, f32 products + f64 sums (:726-730) ------
 struct PxF32 {
     static constexpr int BPP = 4, G = 1, LOG2G = 0;
+    static constexpr bool SRC16 = false;
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -271,7 +315,7 @@ struct PxF32 {
     }
     typedef unsigned long long Store;
     __device__ static __forceinline__ Store bits(Sum v) { return (unsigned long long)__double_as_longlong(v); }
-    __device__ static __forceinline__ float ncc(const Store *sp, double, double)
+    __device__ static __forceinline__ float ncc(const Store *sp, double, double, int, int)
     {
         const double dn = (double)(uint32_t)sp[0];
         const double sx = __longlong_as_double((long long)sp[1]), sy = __longlong_as_double((long long)sp[2]);
@@ -370,7 +414,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     constexpr int OCW = C::OCW, CW = C::CW, GPR = C::GPR, NT = C::NT, NW = C::NW;
 
     int gidx = blockIdx.x;
-    {
+    if (p.point_list) {                                      // list mode: the points another kernel handed over
+        if (gidx >= *p.point_count) return;
+        gidx = p.point_list[gidx];
+    } else {
         const int nb = gridDim.x, per = nb >> 3;
         if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);   // XCD-contiguous point order
     }
@@ -430,7 +477,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // control words: [0] clean queued, [1] dirty queued, [2] cache slots used, [3] cache overflow,
     // [4] null pixels in the window, [5..8] their bounding box (x0,x1,y0,y1), [9] driver decision
     int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // behind the sums
-    if (tid < 16) qcnt[tid] = (tid == 5 || tid == 7) ? (1 << 20) : ((tid == 6 || tid == 8) ? -1 : 0);
+    // ([11..14]: PxU8o only -- min/max of the non-null window and chip pixels)
+    if (tid < 16) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14) ? -1 : 0);
     __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
     auto lookup = [&](int cell) __attribute__((always_inline)) -> float {
@@ -439,6 +487,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
+    int ka = 0, kb = 0;                                      // PxU8o: per-point offsets of chip and window (0 otherwise)
     int bad_win = 0, exc_win = 0;                            // "x < MIN_DN" count (:631) / pixels the NCC loop skips (:723)
     int nbx0 = 1 << 20, nbx1 = -1, nby0 = 1 << 20, nby1 = -1;   // bounding box of the skipped pixels (window coords, dword-granular in x)
     {
@@ -451,10 +500,53 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const uint32_t last_ff = lastp ? P::lowmask(lastp) : 0xffffffffu;
         const uint32_t *gbase = reinterpret_cast<const uint32_t *>(win_pl + ((size_t)wv0 * Wp + (wu0 - pt.sh)) * P::BPP);
         const int gpitch = (Wp * P::BPP) >> 2;
+        // PxU8o: the source planes are u16; four pixels = one aligned uint2
+        const uint2 *gbase16 = reinterpret_cast<const uint2 *>(win_pl + ((size_t)wv0 * Wp + (wu0 - pt.sh)) * 2);
+        const int gpitch16 = Wp >> 2;
+        (void)gbase16; (void)gpitch16;
+        if constexpr (P::SRC16) {
+            // pass 1: local range of the window and of the chip; a point that does not fit 8 bits goes to the u16 kernel
+            int mn = 1 << 20, mx = -1;
+            for (int idx = tid; idx < tot; idx += NT) {
+                const int r = (int)__umulhi((uint32_t)idx, inv);
+                const int c = idx - r * nd;
+                uint32_t keep = 0xffffffffu;
+                if (c == 0) keep &= first_ff;
+                if (c == nd - 1) keep &= last_ff;
+                PxU8o::range4(gbase16[(size_t)r * gpitch16 + c], keep, mn, mx);
+            }
+            int cmn = 1 << 20, cmx = -1;
+            {
+                const unsigned short *c16 = reinterpret_cast<const unsigned short *>(chip_pl);
+                const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
+                for (int q = tid; q < C::NPX; q += NT) {
+                    const int rr = q / CW, cc = q - rr * CW;
+                    const int val = c16[(size_t)(cv0 + rr) * Wp + cu0 + cc];
+                    if (val) { cmn = min(cmn, val); cmx = max(cmx, val); }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64));
+                cmn = min(cmn, __shfl_xor(cmn, o, 64)); cmx = max(cmx, __shfl_xor(cmx, o, 64));
+            }
+            if (lane == 0) { atomicMin(&qcnt[11], mn); atomicMax(&qcnt[12], mx); atomicMin(&qcnt[13], cmn); atomicMax(&qcnt[14], cmx); }
+            __syncthreads();
+            mn = qcnt[11]; mx = qcnt[12]; cmn = qcnt[13]; cmx = qcnt[14];
+            const bool fit = (mx < mn || mx - mn <= 254) && (cmx < cmn || cmx - cmn <= 254);
+            if (!fit) {
+                if (tid == 0) p.fail_list[atomicAdd(p.fail_count, 1)] = gidx;
+                return;
+            }
+            kb = mx < mn ? 0 : mn - 1;
+            ka = cmx < cmn ? 0 : cmn - 1;
+        }
         for (int idx = tid; idx < tot; idx += NT) {
             const int r = (int)__umulhi((uint32_t)idx, inv);
             const int c = idx - r * nd;
-            uint32_t v = gbase[(size_t)r * gpitch + c];
+            uint32_t v;
+            if constexpr (P::SRC16) v = PxU8o::pack(gbase16[(size_t)r * gpitch16 + c], kb);
+            else v = gbase[(size_t)r * gpitch + c];
             uint32_t keep = 0xffffffffu;
             if (c == 0) keep &= first_ff;
             if (c == nd - 1) keep &= last_ff;
@@ -506,13 +598,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const uint32_t sa = (uint32_t)(sap * P::BPP);
         const uint32_t *gbase = reinterpret_cast<const uint32_t *>(chip_pl + ((size_t)cv0 * Wp + (cu0 - sap)) * P::BPP);
         const int gpitch = (Wp * P::BPP) >> 2;
+        const uint2 *gbase16 = reinterpret_cast<const uint2 *>(chip_pl + ((size_t)cv0 * Wp + (cu0 - sap)) * 2);   // PxU8o source
+        const int gpitch16 = Wp >> 2;
+        (void)gbase16; (void)gpitch16;
+        // aligned dword j of chip row `row` (PxU8o: converted from the u16 plane through the chip offset)
+        auto chip_dword = [&](int row, int j) __attribute__((always_inline)) -> uint32_t {
+            if constexpr (P::SRC16) return PxU8o::pack(gbase16[(size_t)row * gpitch16 + j], ka);
+            else return gbase[(size_t)row * gpitch + j];
+        };
         constexpr int NLD = GPR + (P::G > 1 ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < C::RF; i++) {
-            const uint32_t *rp = gbase + (size_t)(l + C::LPC * i) * gpitch;
             uint32_t g[NLD];
 #pragma unroll
-            for (int j = 0; j < NLD; j++) g[j] = rp[j];
+            for (int j = 0; j < NLD; j++) g[j] = chip_dword(l + C::LPC * i, j);
 #pragma unroll
             for (int j = 0; j < GPR; j++) {
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
@@ -529,8 +628,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const int tt = l + C::LPC * k;
             const bool on = tt < C::REM * GPR;
             const int rr = C::RF * C::LPC + (on ? tt / GPR : 0), j = on ? tt % GPR : 0;
-            const uint32_t *rp = gbase + (size_t)rr * gpitch + j;
-            uint32_t a = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], sa) : rp[0];
+            const uint32_t g0 = chip_dword(rr, j);
+            uint32_t a = (P::G > 1) ? alignb(chip_dword(rr, j + (P::G > 1 ? 1 : 0)), g0, sa) : g0;
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
             bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
@@ -664,7 +763,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             __syncthreads();
             if (tid < nb) {
                 const uint32_t pk = ids[dir * (b0 + tid)];
-                nccv[pk >> 16] = P::ncc(sums + 6 * tid, sc_chip, sc_win);
+                nccv[pk >> 16] = P::ncc(sums + 6 * tid, sc_chip, sc_win, ka, kb);
             }
             __syncthreads();
         }
@@ -1071,6 +1170,49 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+{
+    if (a.N <= 0) return hipSuccess;
+    switch (a.ocw) {       // the u8 configurations, fed from u16 planes through per-point offsets
+    case 7: return launch_cfg<PxCfg<PxU8o, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 15: return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 16: return launch_cfg<PxCfg<PxU8o, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<PxCfg<PxU8o, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxU8o, 40, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// Is PxU8o worth trying on this plane?  One workgroup per 128x128 tile: does the tile's non-null range fit 8 bits?
+__global__ __launch_bounds__(256) void range_tiles(const unsigned short *__restrict__ plane, int H, int W, int Wp, int pad, int *out2)
+{
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 128;
+    int mn = 1 << 20, mx = -1;
+    for (int q = threadIdx.x; q < 128 * 128; q += 256) {
+        const int x = x0 + (q & 127), y = y0 + (q >> 7);
+        if (x < W && y < H) {
+            const int v = plane[(size_t)(y + pad) * Wp + x + pad];
+            if (v) { mn = min(mn, v); mx = max(mx, v); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+    __shared__ int smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mn = min(mn, smn[w]); mx = max(mx, smx[w]); }
+        if (mx >= mn) { atomicAdd(&out2[1], 1); if (mx - mn <= 254) atomicAdd(&out2[0], 1); }
+    }
+}
+
+hipError_t launch_range_tiles(const unsigned short *plane, int H, int W, int Wp, int pad, int *d_out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(range_tiles, dim3((W + 127) / 128, (H + 127) / 128), dim3(256), 0, s, plane, H, W, Wp, pad, d_out2);
+    return hipGetLastError();
 }
 
 bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v)

@@ -88,8 +88,9 @@ def test_filtered_passes_end_to_end(api, oracle, name):
         g0, g1 = ctx.get_images(H, W)
         assert_bits_equal(g0, f0, "filtered i0"); assert_bits_equal(g1, f1, "filtered i1")
         fw = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        # gradients of 8-bit data are integers (u8 kernel if they stay below 256), the Laplacian multiples of 1/8
-        assert ctx.last_path() == ("u16_scaled" if name == "laplacian" else "u8_exact" if max(f0.max(), f1.max()) <= 255 else "u16_scaled")
+        # gradients of 8-bit data are integers (u8 kernel if they stay below 256, else the u8 kernel through per-point
+        # offsets with the u16 kernel behind it), the Laplacian multiples of 1/8 (u16 kernel)
+        assert ctx.last_path() == ("u16_scaled" if name == "laplacian" else "u8_exact" if max(f0.max(), f1.max()) <= 255 else "u8_offset")
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
         assert_bits_equal(fw, ref_fw, "forward"); assert_bits_equal(sw, ref_sw, "swapped")
         ctx.filter_images(None)                            # back to the raw pair

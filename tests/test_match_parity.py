@@ -231,3 +231,45 @@ def test_edge_cases(api):
         one = ctx.matching_ncc_dlc_2(c.xyuvav[:1], c.offset, off[:2], uv[:off[1]], c.ocw)
         full = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         assert_bits_equal(one, full[:1])
+
+
+# ---- 9-bit integer imagery (what the gradient filters make of 8-bit images): the u8 kernels through per-point offsets,
+#      with the u16 kernel redoing the points whose chip or window does not fit a local 8-bit range -----------------------
+def nine_bit_case(seed, ocw, wide_frac, null_frac=0.03, shift=(2, -3)):
+    c = synth.make_small(seed=seed, shift=shift, angle_deg=35.0, ocw=ocw, h=300, w=320, dimx=12, dimy=11, null_frac=null_frac,
+                         noise_dn=2, margin=ocw + 40)
+    rng = np.random.default_rng(seed)
+    # centre the 8-bit texture around 256 with a reduced amplitude: values 150..360, local range < 255 almost everywhere
+    def remap(img):
+        out = np.where(img > 0, np.round(150.0 + img * 0.8), 0.0).astype(np.float32)
+        # a few bright spots push some windows / chips over the 8-bit range: those points must take the u16 fallback
+        n = int(wide_frac * out.size / 400)
+        ys = rng.integers(0, out.shape[0], n); xs = rng.integers(0, out.shape[1], n)
+        out[ys, xs] = np.where(out[ys, xs] > 0, 500.0, 0.0)
+        return out
+    c.i0[:] = remap(c.i0); c.i1[:] = remap(c.i1)
+    return c
+
+
+@pytest.mark.parametrize("ocw", [7, 15, 16, 30, 40])
+@pytest.mark.parametrize("wide_frac", [0.0, 0.02, 1.0], ids=["all_fit", "some_fallback", "mostly_fallback"])
+def test_offset_u8_path_vs_oracle(api, oracle, ocw, wide_frac):
+    c = nine_bit_case(seed=500 + ocw, ocw=ocw, wide_frac=wide_frac)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    want_sw = oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        path = ctx.last_path()
+        got_sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
+        ctx.set_path("u16")
+        ref16 = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert ctx.last_path() == "u16_scaled"
+    assert path in ("u8_offset", "u16_scaled")          # the tile estimate decides whether the offset path is tried at all
+    if wide_frac == 0.0:
+        assert path == "u8_offset"
+    assert_bits_equal(got, want, "forward"); assert_bits_equal(got_sw, want_sw, "swapped")
+    assert_bits_equal(ref16, want, "u16 kernel alone")
+    assert (got[:, 2] > -2.5).mean() > 0.5
