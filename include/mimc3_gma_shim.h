@@ -1,6 +1,6 @@
 /*
- * mimc3_gma_shim.h -- struct-level drop-in for the four reference functions on the hot path, with
- * the reference's EXACT names and signatures, implemented on top of libmimc3_hip.so.
+ * mimc3_gma_shim.h -- struct-level drop-in for the reference's functions on the hot path and the stages either
+ * side of it, with the reference's EXACT names and signatures, implemented on top of libmimc3_hip.so.
  *
  *   replaces (declared in the reference's MIMC_module.h)      reference definition
  *   ----------------------------------------------------      -------------------------
@@ -8,6 +8,14 @@
  *   matching_ncc_dlc_2        MIMC_module.h:46                MIMC_module.c:805-842
  *   get_ruv_neighbor          MIMC_module.h:56                MIMC_module.c:1266-1327
  *   get_dpf_pseudosmoothing   MIMC_module.h:58                MIMC_module.c:1986-2312
+ *   get_offset_image          MIMC_module.h:34                MIMC_module.c:33-492     (N4)
+ *   calc_mean_var_num_dp_cluster  MIMC_module.h:49            MIMC_module.c:994-1130   (N1)
+ *   get_dpf0                  MIMC_module.h:53                MIMC_module.c:1224-1263  (N1)
+ *   get_dpf1                  MIMC_module.h:56                MIMC_module.c:1330-1718  (N1)
+ *   GMA_float_conv2           MIMC_module.h:67                MIMC_module.c:2517-2585  (N2)
+ *   mimc2_postprocess         MIMC_module.h:48                MIMC_module.c:892-990    (N3)
+ * These are all the symbols the reference's main() takes from MIMC_module.c: MIMC_main.c + GMA.c + MIMC_misc.c
+ * link against this archive WITHOUT MIMC_module.c (`make -C oracle hybrid` does exactly that as a test).
  *
  * The structs below are layout-compatible re-declarations of the reference's array types
  * (GMA.h:68-91: {int32 ncols; int32 nrows; T **val; T *data;}) and of `param` (MIMC_module.h:9-25,
@@ -50,6 +58,13 @@ GMA_float *matching_ncc_dlc_2(GMA_float *i0, GMA_float *i1, GMA_double *xyuvav, 
 GMA_int32 *get_ruv_neighbor(GMA_double *xyuvav, float radius_neighbor);
 void get_dpf_pseudosmoothing(GMA_int32 *dpf, GMA_float *dpf_dx, GMA_float *dpf_dy, GMA_int32 *ruv_neighbor,
                              GMA_float **mvn_dp, GMA_double *xyuvav);
+
+int get_offset_image(GMA_float *i0, GMA_float *i1, GMA_float **kernel, GMA_double *xyuvav, int32_t *offset, GMA_uint8 *flag_cp);
+GMA_float **calc_mean_var_num_dp_cluster(GMA_float **dp, int32_t num_dpoi);
+GMA_int32 *get_dpf0(GMA_float **mvn_dp, float min_matching_ratio);
+void get_dpf1(GMA_int32 *dpf0, GMA_float *dpf_dx, GMA_float *dpf_dy, GMA_int32 *ruv_neighbor, GMA_float **mvn_dp, GMA_double *xyuvav);
+void GMA_float_conv2(GMA_float *in, GMA_float *kernel, GMA_float *out);
+GMA_float **mimc2_postprocess(GMA_float **dp, GMA_double *xyuvav, float dt);
 
 /* optional: release the shim's device context (images, workspaces) before exit */
 void mimc3_gma_shim_shutdown(void);

@@ -4,6 +4,8 @@
  *
  *   shim_driver match <in.bin> <out.bin>     forward + swapped pass as in main()
  *   shim_driver qm    <in.bin> <out.bin>     get_ruv_neighbor + get_dpf_pseudosmoothing
+ *   shim_driver n1    <in.bin> <out.bin>     calc_mean_var_num_dp_cluster + get_dpf0 + get_dpf1 as mimc2_postprocess
+ *                                            chains them (MIMC_module.c:904-926), and GMA_float_conv2 on a small plane
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -100,12 +102,40 @@ static int run_qm(FILE *fi, FILE *fo)
     return 0;
 }
 
+static int run_n1(FILE *fi, FILE *fo)
+{
+    int32_t h[5]; float fl[4];
+    rd(fi, h, sizeof h); rd(fi, fl, sizeof fl);
+    const int32_t dimx = h[0], dimy = h[1], ndp = h[2], ch = h[3], cw = h[4], N = dimx * dimy;
+    dimx_vmap = dimx; dimy_vmap = dimy; num_grid = N; num_dp = ndp;
+    param_mimc2.meter_per_spacing = fl[0]; dt = fl[2]; param_mimc2.mpp = fl[3];
+    GMA_float **dp = malloc(sizeof(GMA_float *) * (size_t)ndp);
+    for (int32_t k = 0; k < ndp; k++) { dp[k] = mk_float(N, 3); rd(fi, dp[k]->data, 12 * (size_t)N); }
+    GMA_double *xy = mk_double(N, 6);
+    rd(fi, xy->data, 48 * (size_t)N);
+    GMA_float **mvn_dp = calc_mean_var_num_dp_cluster(dp, ndp);
+    GMA_int32 *dpf = get_dpf0(mvn_dp, 0.6f);
+    fwrite(dpf->data, 4, (size_t)N, fo);
+    for (int32_t g = 0; g < N; g++) fwrite(&mvn_dp[g]->nrows, 4, 1, fo);
+    for (int32_t g = 0; g < N; g++) fwrite(mvn_dp[g]->data, 4, 5 * (size_t)mvn_dp[g]->nrows, fo);
+    GMA_int32 *ruv = get_ruv_neighbor(xy, fl[1]);
+    GMA_float *dx = mk_float(dimy, dimx), *dy = mk_float(dimy, dimx);
+    get_dpf1(dpf, dx, dy, ruv, mvn_dp, xy);
+    fwrite(dpf->data, 4, (size_t)N, fo); fwrite(dx->data, 4, (size_t)N, fo); fwrite(dy->data, 4, (size_t)N, fo);
+    /* pre-filter on a ch x cw plane with a 3x3 kernel; `out` comes in dirty (its border is read) */
+    GMA_float *img = mk_float(ch, cw), *ker = mk_float(3, 3), *out = mk_float(ch, cw);
+    rd(fi, img->data, 4 * (size_t)ch * cw); rd(fi, ker->data, 36); rd(fi, out->data, 4 * (size_t)ch * cw);
+    GMA_float_conv2(img, ker, out);
+    fwrite(out->data, 4, (size_t)ch * cw, fo);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc != 4) { fprintf(stderr, "usage: %s match|qm in out\n", argv[0]); return 2; }
+    if (argc != 4) { fprintf(stderr, "usage: %s match|qm|n1 in out\n", argv[0]); return 2; }
     FILE *fi = fopen(argv[2], "rb"), *fo = fopen(argv[3], "wb");
     if (!fi || !fo) { perror("open"); return 2; }
-    int rc = strcmp(argv[1], "match") == 0 ? run_match(fi, fo) : run_qm(fi, fo);
+    int rc = strcmp(argv[1], "match") == 0 ? run_match(fi, fo) : (strcmp(argv[1], "n1") == 0 ? run_n1(fi, fo) : run_qm(fi, fo));
     fclose(fi); fclose(fo);
     mimc3_gma_shim_shutdown();
     return rc;

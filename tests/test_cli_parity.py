@@ -72,6 +72,32 @@ def test_cli_vs_program_live_16bit(cli, tmp_path):
         assert fa == fb, name
 
 
+HYBRID = os.path.join(ROOT, "oracle", "_ref", "MIMC3_main_on_hip")
+
+
+@pytest.mark.skipif(not (os.path.exists(PROG) and os.path.exists(HYBRID)), reason="oracle/_ref programs did not travel to this box")
+def test_reference_main_on_the_shim_vs_reference_program(tmp_path):
+    """INTEGRATION.md option A taken to the end: the reference's OWN main() + GMA.c + MIMC_misc.c linked against
+    libmimc3_gma_shim.a instead of MIMC_module.c (every module function main() calls is then the GPU implementation,
+    through the reference's exact struct-level signatures) writes the same bytes as the reference program."""
+    h, w, dimx, dimy = 360, 400, 13, 11
+    i0, i1 = synth.make_pair(h, w, (1, -2), seed=94, null_frac=0.03, noise_dn=3)
+    xy = synth.make_grid(dimx, dimy, 70, 70, (w - 140) // dimx, (h - 140) // dimy, 1000.0, angle_deg=70.0)
+    rng = np.random.default_rng(94)
+    slow = rng.random(dimx * dimy) < 0.6
+    xy[slow, 4] = rng.uniform(-5, 5, slow.sum()); xy[slow, 5] = rng.uniform(-5, 5, slow.sum())
+    t0, t1 = "20230501000000", "20230513000000"
+    os.makedirs(tmp_path / "a"); os.makedirs(tmp_path / "b")
+    a = write_inputs(str(tmp_path / "a"), i0, i1, xy, t0, t1)
+    b = write_inputs(str(tmp_path / "b"), i0, i1, xy, t0, t1)
+    subprocess.run([PROG] + a, check=True, env=dict(os.environ, MIMC3_REF_SEED="9"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run([HYBRID] + b, env=dict(os.environ, MIMC3_CP_SEED="9"), capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    for k in OUTS:
+        name = f"vmap_{t0}_{t1}_{k}.GMA"
+        assert open(f"{a[3]}/{name}", "rb").read() == open(f"{b[3]}/{name}", "rb").read(), name
+
+
 def test_cli_early_exits(cli, tmp_path):
     """vmap.tar already there -> skip (MIMC_main.c:122-130); no control points -> empty vmap.tar (:246-252); both -1"""
     i0, i1 = synth.make_pair(300, 320, (1, 1), seed=93)
