@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """N1 at BASELINE C5 scale (500x400 = 200k grid points, 32 passes): HIP vs oracle, and device times.
-Test infrastructure (imports oracle/): run on the GPU box, e.g.  gpurun -- python tools/n1_fullsize.py"""
+Test infrastructure (imports oracle/): run on the GPU box, e.g.  gpurun -- python tests/fullsize/n1_fullsize.py"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mimc3_amd import api, synth  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402

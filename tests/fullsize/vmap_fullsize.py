@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The whole program at BASELINE C2 scale (4096^2 pair, 500x400 = 200k grid points, 32 matcher passes): the unmodified
 reference program (oracle/_ref/MIMC3_ref, CPU, all host cores) vs the MIMC3_hip command line vs mimc3_vmap in-process.
-Outputs compared byte for byte.  Test infrastructure; run on the GPU box:  gpurun -- python tools/vmap_fullsize.py"""
+Outputs compared byte for byte.  Test infrastructure; run on the GPU box:  gpurun -- python tests/fullsize/vmap_fullsize.py"""
 import json
 import os
 import subprocess
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fileio  # noqa: E402
 from mimc3_amd import synth  # noqa: E402
