@@ -161,8 +161,9 @@ int mimc3_float_conv2_dev(mimc3_ctx *ctx, const float *d_in, int32_t H, int32_t 
 /*      Filter the context's resident pair on the device and make the filtered pair the one the matcher uses
  *      (what MIMC_main.c:302-350 does with host copies for its 24 filtered passes).  Like the reference, the two
  *      output planes are created once per pair (zeros) and REUSED by consecutive calls, so the border a filter
- *      leaves behind is input to the next one; mimc3_ctx_set_images* starts over.  kernel = NULL goes back to
- *      the pair as handed over.  Nothing crosses PCIe.
+ *      leaves behind is input to the next one; mimc3_ctx_set_images* starts over, and so does kernel = NULL,
+ *      which goes back to the pair as handed over (one run of the reference program = one such sequence).
+ *      Nothing crosses PCIe.
  *      mimc3_ctx_get_images downloads the pair currently in use (either pointer may be NULL). --------- */
 int mimc3_ctx_filter_images(mimc3_ctx *ctx, const float *kernel, int32_t kh, int32_t kw);
 int mimc3_ctx_get_images(mimc3_ctx *ctx, float *i0, float *i1);

@@ -663,8 +663,9 @@ extern "C" int mimc3_ctx_filter_images(mimc3_ctx *c, const float *kernel, int32_
     if (!c) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_filter_images: ctx is NULL");
     if (!c->raw_i0 || !c->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_ctx_filter_images: images not set");
     HIP_TRY(hipSetDevice(c->device));
-    if (!kernel) {                                   // back to the pair as handed over
+    if (!kernel) {                                   // back to the pair as handed over; the next filter starts from fresh planes
         c->d_i0 = c->raw_i0; c->d_i1 = c->raw_i1;
+        c->filt_live = false;
         return prepare_u8(c);
     }
     const size_t bytes = sizeof(float) * (size_t)c->H * c->W;

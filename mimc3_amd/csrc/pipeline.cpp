@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include "../../include/mimc3_hip.h"
@@ -148,6 +149,32 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     int32_t off[2] = {0, 0}, st = -1;
     StageClock clk;
     hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+
+    // ---- pivots per chip size (:264, :316): host geometry (libm-exact, threaded) that depends on nothing the CP stage
+    //      produces, so it runs on a host thread WHILE the device measures the CP offset; results in pinned memory
+    struct HostPiv {
+        std::vector<int64_t> off; void *uv = nullptr; int64_t total = 0; int32_t mn = 0, mu = 0, mv = 0;
+        ~HostPiv() { if (uv) (void)hipHostFree(uv); }
+    };
+    HostPiv hp[4];
+    int piv_rc = 0;
+    std::string piv_err;
+    const float mpp = res->mpp;
+    std::thread piv_worker([&]() {
+        for (int c = 0; c < 4 && !piv_rc; c++) {
+            hp[c].off.resize((size_t)N + 1);
+            int rc = mimc3_get_uv_pivot(xyuvav, N, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
+            if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
+                piv_rc = MIMC3_ENODEV; piv_err = "mimc3_vmap: hipHostMalloc for the pivots failed"; break;
+            }
+            if (!rc) rc = mimc3_get_uv_pivot(xyuvav, N, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
+                                             static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
+            if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), N, &hp[c].mn, &hp[c].mu, &hp[c].mv);
+            if (rc) { piv_rc = rc; piv_err = mimc3_last_error(); }       // the message is thread-local: carry it over
+        }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{piv_worker};
+
     RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
     RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
     res->cp_status = st;
@@ -171,36 +198,24 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     HIP_TRY(d_out5.alloc(20 * n));
     HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
 
-    // ---- pivots per chip size (:264, :316), forward and negated (:272-279), resident for all four image variants.
-    //      Host geometry (libm-exact, threaded) into ONE pinned staging buffer; the negated copy is made on the device.
+    // ---- pivots: forward and negated (:272-279) copies resident for all four image variants
     struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; int64_t total = 0; };
     Piv piv[4];
-    {
-        std::vector<int64_t> po[4];
-        int64_t cap = 0;
-        for (int c = 0; c < 4; c++) {
-            po[c].resize(n + 1);
-            RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po[c].data(), nullptr, 0, &piv[c].total));
-            cap = piv[c].total > cap ? piv[c].total : cap;
-        }
-        struct Pinned { void *p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } stage;
-        HIP_TRY(hipHostMalloc(&stage.p, 8 * (size_t)cap, hipHostMallocDefault));
-        int32_t *pu = static_cast<int32_t *>(stage.p);
-        for (int c = 0; c < 4; c++) {
-            int64_t total = 0;
-            RC_TRY(mimc3_get_uv_pivot(xyuvav, N, dt, res->mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, po[c].data(), pu, cap, &total));
-            RC_TRY(mimc3_pivot_extent(pu, po[c].data(), N, &piv[c].mn, &piv[c].mu, &piv[c].mv));
-            HIP_TRY(piv[c].uv.alloc(8 * (size_t)total));
-            HIP_TRY(piv[c].uvn.alloc(8 * (size_t)total));
-            HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
-            HIP_TRY(hipMemcpyAsync(piv[c].uv.p, pu, 8 * (size_t)total, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(piv[c].off.p, po[c].data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
-            RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv.as<int32_t>(), piv[c].uvn.as<int32_t>(), total, s));
-            HIP_TRY(hipStreamSynchronize(s));               // the staging buffer is refilled for the next chip size
-        }
+    piv_worker.join();
+    if (piv_rc) return mimc3::fail(piv_rc, piv_err);
+    for (int c = 0; c < 4; c++) {
+        const int64_t total = hp[c].total;
+        piv[c].mn = hp[c].mn; piv[c].mu = hp[c].mu; piv[c].mv = hp[c].mv; piv[c].total = total;
+        HIP_TRY(piv[c].uv.alloc(8 * (size_t)total));
+        HIP_TRY(piv[c].uvn.alloc(8 * (size_t)total));
+        HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
+        HIP_TRY(hipMemcpyAsync(piv[c].uv.p, hp[c].uv, 8 * (size_t)total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(piv[c].off.p, hp[c].off.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+        RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv.as<int32_t>(), piv[c].uvn.as<int32_t>(), total, s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
 
-    clk.mark("pivots (host) + upload", s);
+    clk.mark("pivots: join + upload", s);
     // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
     for (int kk = -1; kk <= 2; kk++) {
         if (kk >= 0) {

@@ -115,3 +115,8 @@ def test_three_filters_reuse_the_output_planes(api, oracle):
         ctx.set_images(c.i0, c.i1)                          # a new pair starts from zero planes again
         ctx.filter_images(KERNELS["laplacian"])
         assert_bits_equal(ctx.get_images(H, W)[0], oracle.float_conv2(c.i0, KERNELS["laplacian"]), "fresh")
+        ctx.filter_images(KERNELS["ddx"])                   # inherits the Laplacian's border ...
+        ctx.filter_images(None)                             # ... until the sequence is ended: back to raw, fresh planes next
+        assert_bits_equal(ctx.get_images(H, W)[0], c.i0, "raw again")
+        ctx.filter_images(KERNELS["ddx"])
+        assert_bits_equal(ctx.get_images(H, W)[0], oracle.float_conv2(c.i0, KERNELS["ddx"]), "fresh after None")

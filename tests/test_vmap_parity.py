@@ -35,6 +35,9 @@ def test_vmap_vs_oracle_chain(api, oracle, case):
     with api.Context(0) as ctx:
         ctx.set_images(i0, i1)
         got = ctx.vmap(xy, dt, cp_seed=7, num_cp_min=20)
+        again = ctx.vmap(xy, dt, cp_seed=7, num_cp_min=20)      # a second run on the same context = a second program run
+    for k in ("vx", "vy", "ex", "ey", "qual"):
+        assert_bits_equal(again[k], got[k], k + " (repeat)")
     assert ref["cp_status"] == got["cp_status"] == 1
     assert got["offset_cp"] == ref["offset_cp"] == case["shift"]
     assert (got["dimx"], got["dimy"]) == (ref["dimx"], ref["dimy"])
