@@ -393,12 +393,13 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
     return acc;
 }
 
+static constexpr int kStatW = 12;      // diagnostics: 8 phase clocks + cell counts (clean, dirty, evaluate calls)
 static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in LDS before the f64 finish
 
 #define MIMC3_STAMP(i)                                                                         \
     if (p.stats) {                                                                             \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
-        if (threadIdx.x == 0) p.stats[8 * (size_t)blockIdx.x + i] += t_now - t_prev;                   \
+        if (threadIdx.x == 0) p.stats[kStatW * (size_t)blockIdx.x + i] += t_now - t_prev;                   \
         t_prev = t_now;                                                                        \
     }
 
@@ -802,6 +803,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         }
         {   // evaluate everything queued, then empty the queue (the only call site of `evaluate`)
             const int nA = qcnt[0], nB = qcnt[1];
+            if (p.stats && tid == 0) {
+                p.stats[kStatW * (size_t)blockIdx.x + 8] += nA; p.stats[kStatW * (size_t)blockIdx.x + 9] += nB;
+                p.stats[kStatW * (size_t)blockIdx.x + 10] += (nA + nB) ? 1 : 0;
+            }
             __syncthreads();
             if (tid < 2) qcnt[tid] = 0;
             evaluate(list, 1, nA, clean_mode);
@@ -1123,22 +1128,24 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     static size_t stats_n = 0;
     if (want_stats && stats_n < (size_t)nb) {
         if (d_stats) (void)hipFree(d_stats);
-        (void)hipMalloc(&d_stats, 8 * sizeof(unsigned long long) * (size_t)nb);
+        (void)hipMalloc(&d_stats, kStatW * sizeof(unsigned long long) * (size_t)nb);
         stats_n = nb;
     }
     a.stats = want_stats ? d_stats : nullptr;
-    if (want_stats) (void)hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long) * (size_t)nb, stream);
+    if (want_stats) (void)hipMemsetAsync(d_stats, 0, kStatW * sizeof(unsigned long long) * (size_t)nb, stream);
     hipLaunchKernelGGL(match_ncc_dlc_px<C>, dim3(nb), dim3(C::NT), off, stream, a);
     if (want_stats) {
         (void)hipStreamSynchronize(stream);
-        unsigned long long *hh = (unsigned long long *)malloc(8 * sizeof(unsigned long long) * (size_t)nb);
-        (void)hipMemcpy(hh, d_stats, 8 * sizeof(unsigned long long) * (size_t)nb, hipMemcpyDeviceToHost);
-        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t b = 0; b < (size_t)nb; b++) for (int i = 0; i < 8; i++) h[i] += hh[8 * b + i];
+        unsigned long long *hh = (unsigned long long *)malloc(kStatW * sizeof(unsigned long long) * (size_t)nb);
+        (void)hipMemcpy(hh, d_stats, kStatW * sizeof(unsigned long long) * (size_t)nb, hipMemcpyDeviceToHost);
+        unsigned long long h[kStatW] = {0};
+        for (size_t b = 0; b < (size_t)nb; b++) for (int i = 0; i < kStatW; i++) h[i] += hh[kStatW * b + i];
         free(hh);
         fprintf(stderr, "[mimc3 u8 stats] cycles/point: stage %.0f chip %.0f request %.0f eval+fit %.0f spec %.0f pre-replay %.0f replay-loop %.0f publish %.0f\n",
                 (double)h[0] / a.N, (double)h[1] / a.N, (double)h[2] / a.N, (double)h[3] / a.N, (double)h[4] / a.N,
                 (double)h[5] / a.N, (double)h[6] / a.N, (double)h[7] / a.N);
+        fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches\n",
+                (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N);
     }
     return hipGetLastError();
 }
