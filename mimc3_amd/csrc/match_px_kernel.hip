@@ -335,8 +335,12 @@ struct PxCfg {
     static constexpr int NW = NW_, NT = 64 * NW_;            // waves / threads per grid point (one workgroup)
     static constexpr int CW = 2 * OCW + 1, NPX = CW * CW;
     static constexpr int GPR = (CW + P::G - 1) / P::G;       // dwords per chip row
-    static constexpr int RF = CW / LPC;                      // full rounds: rows l + LPC*i
-    static constexpr int REM = CW - RF * LPC;                // leftover rows, split into single-group tasks
+    // A chip with fewer rows than the group has lanes (61 rows on 64 lanes, 15 on 16, 31 on 32) is ONE row round with a
+    // few idle lanes (they hold zeros and read the window's all-zero T4 row) instead of being all "tail": row tasks have
+    // compile-time pad masks and contiguous LDS reads, tail tasks derive their masks from the chip dword by dword.
+    static constexpr bool SHORT = CW < LPC;
+    static constexpr int RF = SHORT ? 1 : CW / LPC;          // full rounds: rows l + LPC*i
+    static constexpr int REM = SHORT ? 0 : CW - RF * LPC;    // leftover rows, split into single-group tasks
     static constexpr int TT = (REM * GPR + LPC - 1) / LPC;   // tail tasks per lane
     static constexpr int LASTN = CW - P::G * (GPR - 1);      // valid pixels of the last dword of a row (1..G)
     static constexpr uint32_t LASTFF = P::lowmask_c(LASTN);
@@ -369,6 +373,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
 #pragma unroll
     for (int i = 0; i < C::RF; i++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + (l + C::LPC * i) * pt.PW);
+        if (C::SHORT && l >= C::CW) rp = reinterpret_cast<const uint32_t *>(W + (pt.Dy2 - 1) * pt.PW);   // idle lane: the zero row
         uint32_t w[NLD];
 #pragma unroll
         for (int j = 0; j < NLD; j++) w[j] = rp[j];
@@ -611,12 +616,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
         for (int i = 0; i < C::RF; i++) {
             uint32_t g[NLD];
+            const bool rowok = !C::SHORT || l < C::CW;                  // SHORT: lanes past the last chip row hold zeros
 #pragma unroll
-            for (int j = 0; j < NLD; j++) g[j] = chip_dword(l + C::LPC * i, j);
+            for (int j = 0; j < NLD; j++) g[j] = chip_dword(rowok ? l + C::LPC * i : 0, j);
 #pragma unroll
             for (int j = 0; j < GPR; j++) {
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
-                const uint32_t pff = (j == GPR - 1) ? C::LASTFF : 0xffffffffu;
+                const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
                 a &= pff;
                 bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
                 a = P::sanitize(a, pt.thr);
