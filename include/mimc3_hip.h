@@ -231,6 +231,15 @@ typedef struct mimc3_vmap_result {
 } mimc3_vmap_result;
 int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params,
                float *vx, float *vy, float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res);
+/*      The same in two steps, for a multi-GPU driver (grid points are independent in the matcher):
+ *      mimc3_vmap_passes = geometry + CP offset on the WHOLE grid + the 32 passes for grid points [lo, hi) only, into
+ *      d_dp [32][hi-lo][3] (device, pass-major); the caller all-gathers the blocks into [32][N][3] and every rank
+ *      calls mimc3_vmap_finish (post-processing, unit conversion) with the `res` its own passes call filled.
+ *      mimc3_vmap is passes(0, N) + finish. ---------------------------------------------------------------------- */
+int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params,
+                      int32_t lo, int32_t hi, float *d_dp, uint8_t *flag_cp, mimc3_vmap_result *res);
+int mimc3_vmap_finish(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params,
+                      const float *d_dp, float *vx, float *vy, float *ex, float *ey, float *qual, mimc3_vmap_result *res);
 
 /*      small device helpers the driver is built from: the context's own stream; (du,dv) -> (-du,-dv) of a swapped
  *      pass (MIMC_main.c:289-293); cluster map -> five planes (mimc2_postprocess :937-970 /

@@ -99,6 +99,10 @@ _lib.mimc3_postprocess.argtypes = [_vp, _f32p, C.c_int32, _f64p, C.c_int32, C.c_
                                    C.c_float, C.c_int32, _f32p]
 _lib.mimc3_vmap.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), _f32p, _f32p, _f32p, _f32p, _f32p,
                             np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(VmapResult)]
+_lib.mimc3_vmap_passes.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), C.c_int32, C.c_int32, _vp,
+                                   np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(VmapResult)]
+_lib.mimc3_vmap_finish.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), _vp, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                   C.POINTER(VmapResult)]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
@@ -251,13 +255,9 @@ class Context:
                                       meter_per_spacing, radius_dpf1, radius_ps, qm_max_sweeps, out.reshape(-1)), "mimc2_postprocess")
         return out
 
-    def vmap(self, xyuvav, dt, kernels=CLI_KERNELS, cp_seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, aw_sf=1.8,
-             radius_neighbor_dpf1=3.0, radius_neighbor_ps=5.0, num_cp_max=500, num_cp_min=50, ratio_cp=0.03, thres_spd_cp=10.0,
-             qm_max_sweeps=101):
-        """MIMC_main.c:203-402 on the resident pair. Returns dict(vx, vy, ex, ey, qual [dimy][dimx], flag_cp, + the
-        scalar fields of mimc3_vmap_result); arrays are None when cp_status == -1."""
-        xy = np.ascontiguousarray(xyuvav, np.float64)
-        n = xy.shape[0]
+    @staticmethod
+    def _vmap_params(kernels=CLI_KERNELS, cp_seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, aw_sf=1.8, radius_neighbor_dpf1=3.0,
+                     radius_neighbor_ps=5.0, num_cp_max=500, num_cp_min=50, ratio_cp=0.03, thres_spd_cp=10.0, qm_max_sweeps=101):
         ks = [np.ascontiguousarray(k, np.float32) for k in kernels]
         p = VmapParams()
         p.vec_ocw[:] = list(vec_ocw)
@@ -267,16 +267,49 @@ class Context:
         for i, k in enumerate(ks):
             p.kernel[i] = k.ctypes.data
             p.kdim[i][0], p.kdim[i][1] = k.shape
-        planes = [np.empty(n, np.float32) for _ in range(5)]
-        flag = np.zeros(n, np.uint8)
-        r = VmapResult()
-        _check(_lib.mimc3_vmap(self._h, xy, n, dt, C.byref(p), *planes, flag, C.byref(r)), "vmap")
+        return p, ks                      # ks keeps the kernel arrays alive
+
+    @staticmethod
+    def _vmap_out(r, flag, planes):
         out = dict(dimx=r.dimx, dimy=r.dimy, mpp=r.mpp, spacing_grid=r.spacing_grid, meter_per_spacing=r.meter_per_spacing,
                    cp_status=r.cp_status, offset_cp=(r.offset_cp[0], r.offset_cp[1]), cp_subint=(r.cp_subint[0], r.cp_subint[1]),
                    flag_cp=flag)
         for name, a in zip(("vx", "vy", "ex", "ey", "qual"), planes):
             out[name] = a.reshape(r.dimy, r.dimx) if r.cp_status > 0 else None
         return out
+
+    def vmap(self, xyuvav, dt, **kw):
+        """MIMC_main.c:203-402 on the resident pair (keywords: see _vmap_params; defaults = MIMC_main.c:134-194).
+        Returns dict(vx, vy, ex, ey, qual [dimy][dimx], flag_cp, + the scalar fields of mimc3_vmap_result); the planes
+        are None when cp_status == -1."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        n = xy.shape[0]
+        p, _keep = self._vmap_params(**kw)
+        planes = [np.empty(n, np.float32) for _ in range(5)]
+        flag = np.zeros(n, np.uint8)
+        r = VmapResult()
+        _check(_lib.mimc3_vmap(self._h, xy, n, dt, C.byref(p), *planes, flag, C.byref(r)), "vmap")
+        return self._vmap_out(r, flag, planes)
+
+    def vmap_passes(self, xyuvav, dt, lo, hi, d_dp, **kw):
+        """mimc3_vmap_passes: CP offset on the whole grid + the 32 passes for grid points [lo, hi) into the device tensor
+        d_dp [32][hi-lo][3] (pass its data_ptr()).  Returns (VmapResult, flag_cp)."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        p, _keep = self._vmap_params(**kw)
+        flag = np.zeros(xy.shape[0], np.uint8)
+        r = VmapResult()
+        _check(_lib.mimc3_vmap_passes(self._h, xy, xy.shape[0], dt, C.byref(p), lo, hi, d_dp, flag, C.byref(r)), "vmap_passes")
+        return r, flag
+
+    def vmap_finish(self, xyuvav, dt, d_dp_full, r, flag, **kw):
+        """mimc3_vmap_finish on the complete candidate tensor [32][N][3] (device pointer); same dict as vmap()."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        n = xy.shape[0]
+        p, _keep = self._vmap_params(**kw)
+        planes = [np.empty(n, np.float32) for _ in range(5)]
+        if r.cp_status > 0:
+            _check(_lib.mimc3_vmap_finish(self._h, xy, n, dt, C.byref(p), d_dp_full, *planes, C.byref(r)), "vmap_finish")
+        return self._vmap_out(r, flag, planes)
 
     # -- N4: control-point offset -----------------------------------------------------------------
     def get_offset_image(self, xyuvav, kernels, seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500, num_cp_min=50,

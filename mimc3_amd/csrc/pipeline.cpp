@@ -120,24 +120,35 @@ extern "C" int mimc3_postprocess(mimc3_ctx *ctx, const float *dp, int32_t ndp, c
     return 0;
 }
 
-extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, float *vx, float *vy,
-                          float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res)
+namespace {
+
+// grid geometry (MIMC_main.c:209-223)
+int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
 {
-    if (!ctx || !xyuvav || !p || !vx || !vy || !ex || !ey || !qual || !flag_cp || !res || N < 2)
-        return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: bad argument");
-    int32_t H = 0, W = 0;
-    RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
-    std::memset(res, 0, sizeof(*res));
-    // ---- grid geometry (MIMC_main.c:209-223)
     int32_t g = 1;
     for (; g < N; g++)
         if ((int)xyuvav[6 * (size_t)g + 2] == (int)xyuvav[2]) break;
-    const int32_t dimx = g, dimy = N / dimx;
-    res->dimx = dimx; res->dimy = dimy;
+    res->dimx = g; res->dimy = N / g;
     res->mpp = (float)((xyuvav[6] - xyuvav[0]) / (xyuvav[8] - xyuvav[2]));
     res->spacing_grid = (float)(xyuvav[8] - xyuvav[2]);
     res->meter_per_spacing = (float)(xyuvav[6] - xyuvav[0]);
-    if (dimx * dimy != N) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: xyuvav is not a full dimy x dimx grid");
+    if (res->dimx * res->dimy != N) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: xyuvav is not a full dimy x dimx grid");
+    return 0;
+}
+
+}  // namespace
+
+// CP offset on the whole grid, then the 32 matcher passes for grid points [lo, hi) only (grid points are independent in
+// the matcher: this is the unit a multi-GPU driver shards).  d_dp: device, [32][hi-lo][3] pass-major.
+extern "C" int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, int32_t lo,
+                                 int32_t hi, float *d_dp, uint8_t *flag_cp, mimc3_vmap_result *res)
+{
+    if (!ctx || !xyuvav || !p || !flag_cp || !res || N < 2 || lo < 0 || hi > N || lo > hi || (hi > lo && !d_dp))
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_passes: bad argument");
+    int32_t H = 0, W = 0;
+    RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
+    std::memset(res, 0, sizeof(*res));
+    RC_TRY(vmap_geometry(xyuvav, N, res));
 
     // ---- CP offset (:240-256)
     mimc3_cp_params cp{};
@@ -149,6 +160,8 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     int32_t off[2] = {0, 0}, st = -1;
     StageClock clk;
     hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+    const int32_t ns = hi - lo;
+    const double *xs = xyuvav + 6 * (size_t)lo;
 
     // ---- pivots per chip size (:264, :316): host geometry (libm-exact, threaded) that depends on nothing the CP stage
     //      produces, so it runs on a host thread WHILE the device measures the CP offset; results in pinned memory
@@ -161,15 +174,15 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     std::string piv_err;
     const float mpp = res->mpp;
     std::thread piv_worker([&]() {
-        for (int c = 0; c < 4 && !piv_rc; c++) {
-            hp[c].off.resize((size_t)N + 1);
-            int rc = mimc3_get_uv_pivot(xyuvav, N, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
+        for (int c = 0; c < 4 && !piv_rc && ns > 0; c++) {
+            hp[c].off.resize((size_t)ns + 1);
+            int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
             if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
                 piv_rc = MIMC3_ENODEV; piv_err = "mimc3_vmap: hipHostMalloc for the pivots failed"; break;
             }
-            if (!rc) rc = mimc3_get_uv_pivot(xyuvav, N, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
+            if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
                                              static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
-            if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), N, &hp[c].mn, &hp[c].mu, &hp[c].mv);
+            if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
             if (rc) { piv_rc = rc; piv_err = mimc3_last_error(); }       // the message is thread-local: carry it over
         }
     });
@@ -181,22 +194,21 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     if (st < 0) return 0;                                   // the CLI touches vmap.tar and gives up (:248-252)
     res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1];
     clk.mark("control-point offset", s);
+    if (ns == 0) { piv_worker.join(); return 0; }
 
     // ---- the reference refuses nothing, it reads out of bounds; this library refuses (see mimc3_match_ncc_dlc)
     int ocw_max = 0;
     for (int k = 0; k < 4; k++) ocw_max = p->vec_ocw[k] > ocw_max ? p->vec_ocw[k] : ocw_max;
-    for (int32_t i = 0; i < N; i++) {
+    for (int32_t i = lo; i < hi; i++) {
         const int32_t u0 = (int32_t)xyuvav[6 * (size_t)i + 2], v0 = (int32_t)xyuvav[6 * (size_t)i + 3];
         if (u0 - ocw_max < 0 || u0 + ocw_max >= W || v0 - ocw_max < 0 || v0 + ocw_max >= H)
             return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: grid point " + std::to_string(i) + " chip leaves the image");
     }
 
-    const size_t n = (size_t)N;
-    Buf d_xy, d_dp, d_out5;
+    const size_t n = (size_t)ns;
+    Buf d_xy;
     HIP_TRY(d_xy.alloc(48 * n));
-    HIP_TRY(d_dp.alloc(12 * n * 32));
-    HIP_TRY(d_out5.alloc(20 * n));
-    HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_xy.p, xs, 48 * n, hipMemcpyHostToDevice, s));
 
     // ---- pivots: forward and negated (:272-279) copies resident for all four image variants
     struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; int64_t total = 0; };
@@ -224,20 +236,37 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
         }
         for (int c = 0; c < 4; c++) {
             const int slot = (kk + 1) * 8 + c * 2;
-            float *fw = d_dp.as<float>() + (size_t)slot * n * 3, *sw = fw + n * 3;
-            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), N, off[0], off[1], piv[c].uv.as<int32_t>(), piv[c].off.as<int64_t>(),
+            float *fw = d_dp + (size_t)slot * n * 3, *sw = fw + n * 3;
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), ns, off[0], off[1], piv[c].uv.as<int32_t>(), piv[c].off.as<int64_t>(),
                                            piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 0, fw, s));
-            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), N, -off[0], -off[1], piv[c].uvn.as<int32_t>(), piv[c].off.as<int64_t>(),
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), ns, -off[0], -off[1], piv[c].uvn.as<int32_t>(), piv[c].off.as<int64_t>(),
                                            piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 1, sw, s));
-            RC_TRY(mimc3_negate_uv_dev(ctx, sw, N, s));      // :289-293
+            RC_TRY(mimc3_negate_uv_dev(ctx, sw, ns, s));     // :289-293
         }
         clk.mark("8 matcher passes", s);
     }
     RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+    HIP_TRY(hipStreamSynchronize(s));                       // d_dp is complete (and the pivot buffers are freed on return)
     clk.mark("back to the raw pair", s);
+    return 0;
+}
 
+// Post-processing of the complete candidate tensor d_dp [32][N][3] (device) and the unit conversion (:353-402).
+// `res` is the one mimc3_vmap_passes filled (its geometry is used, cp_subint is added).
+extern "C" int mimc3_vmap_finish(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, const float *d_dp,
+                                 float *vx, float *vy, float *ex, float *ey, float *qual, mimc3_vmap_result *res)
+{
+    if (!ctx || !xyuvav || !p || !d_dp || !vx || !vy || !ex || !ey || !qual || !res || N < 2 || res->dimx * res->dimy != N)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_finish: bad argument (res must come from mimc3_vmap_passes)");
+    StageClock clk;
+    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+    const size_t n = (size_t)N;
+    Buf d_xy, d_out5;
+    HIP_TRY(d_xy.alloc(48 * n));
+    HIP_TRY(d_out5.alloc(20 * n));
+    HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
     // ---- postprocess (:353)
-    RC_TRY(mimc3_postprocess_dev(ctx, d_dp.as<float>(), 32, xyuvav, d_xy.as<double>(), dimx, dimy, dt, res->mpp, res->meter_per_spacing,
+    RC_TRY(mimc3_postprocess_dev(ctx, d_dp, 32, xyuvav, d_xy.as<double>(), res->dimx, res->dimy, dt, res->mpp, res->meter_per_spacing,
                                  p->radius_neighbor_dpf1, p->radius_neighbor_ps, p->qm_max_sweeps > 0 ? p->qm_max_sweeps : 101,
                                  d_out5.as<float>(), s));
     clk.mark("postprocess", s);
@@ -265,4 +294,16 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
     }
     clk.mark("download + unit conversion", s);
     return 0;
+}
+
+extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, float *vx, float *vy,
+                          float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res)
+{
+    if (!ctx || !xyuvav || !p || !vx || !vy || !ex || !ey || !qual || !flag_cp || !res || N < 2)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: bad argument");
+    Buf d_dp;
+    HIP_TRY(d_dp.alloc(12 * (size_t)N * 32));
+    RC_TRY(mimc3_vmap_passes(ctx, xyuvav, N, dt, p, 0, N, d_dp.as<float>(), flag_cp, res));
+    if (res->cp_status < 0) return 0;
+    return mimc3_vmap_finish(ctx, xyuvav, N, dt, p, d_dp.as<float>(), vx, vy, ex, ey, qual, res);
 }
