@@ -564,12 +564,18 @@ extern "C" int mimc3_get_dpf1_dev(mimc3_ctx *c, int32_t dimy, int32_t dimx, int3
     if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 init launch");
     // the reference's sweep count is data dependent and unbounded: enqueue batches, poll the device's done flag
     int32_t st[mimc3::kD1Words] = {0};
+    // The reference's loop has no bound: a point whose fitted value is NaN counts as "processed" in every sweep and
+    // keeps its inner while alive for ever (:1526, :1533-1545).  This library gives up instead of hanging the device.
+    const int kMaxBatches = 1 << 15;                      // 2^20 sweeps
+    int batches = 0;
     for (;;) {
         e = mimc3::launch_dpf1_sweeps(a, 32, s);
         if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 sweep launch");
         HIP_TRY(hipMemcpyAsync(st, a.state, sizeof(st), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (st[mimc3::kD1Done]) break;
+        if (++batches >= kMaxBatches)
+            return mimc3::fail(MIMC3_ESTATE, "mimc3_get_dpf1: no termination after 2^20 sweeps (the reference would loop for ever on this input)");
     }
     e = mimc3::launch_dpf1_finish(a, s);
     if (e != hipSuccess) return mimc3::hip_fail(e, "dpf1 finish launch");
