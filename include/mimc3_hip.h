@@ -56,7 +56,7 @@ int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i
  *   4 = the u8 kernel read through per-point offsets, for INTEGER images of kind 3 whose values stay within an
  *       8-bit range locally (the gradient filters of 8-bit images); the few points whose chip or window does
  *       not fit are redone by kernel 3 right behind.  Exact like 3 (same integer sums, rebuilt from q - k);
- *   2 = register-tiled f32 kernel (any f32 imagery) when ocw is one of 7, 15, 16;
+ *   2 = register-tiled f32 kernel (any f32 imagery, e.g. 16-bit DN) when ocw is one of 7, 15, 16, 30, 40;
  *   0 = general f32 kernel (any ocw, any window size) otherwise.
  * All three give results bit-identical to the reference on integral-DN data.  mode 1 forces kernel 0,
  * mode 2 skips the integer kernels, mode 3 skips only the u8 kernel (tests use them to cover every kernel

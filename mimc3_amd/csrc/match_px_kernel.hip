@@ -1158,7 +1158,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
 {
-    if (!(ocw == 7 || ocw == 15 || ocw == 16)) return false;     // chip rows must fit the register image
+    if (!(ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 40)) return false;     // chip rows must fit the register image
     return max_reach_u + 12 <= kU8Pad && max_reach_v + 12 <= kU8Pad && max_reach_u <= 120 && max_reach_v <= 120;
 }
 
@@ -1169,6 +1169,8 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxF32, 30, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxF32, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -18,7 +18,7 @@ def api():
 U8_OCW = (7, 15, 16, 30, 32, 40)   # chip sizes the exact u8 kernel is instantiated for
 
 
-F32T_OCW = (7, 15, 16)              # chip sizes of the register-tiled f32 kernel
+F32T_OCW = (7, 15, 16, 30, 40)      # chip sizes of the register-tiled f32 kernel
 
 
 def expected_path(mode, i0, ocw, i1=None):
@@ -272,4 +272,33 @@ def test_offset_u8_path_vs_oracle(api, oracle, ocw, wide_frac):
         assert path == "u8_offset"
     assert_bits_equal(got, want, "forward"); assert_bits_equal(got_sw, want_sw, "swapped")
     assert_bits_equal(ref16, want, "u16 kernel alone")
+    assert (got[:, 2] > -2.5).mean() > 0.5
+
+
+@pytest.mark.parametrize("ocw", [7, 15, 30, 40])
+@pytest.mark.parametrize("kind", ["16bit", "float"])
+def test_16bit_and_float_imagery_on_the_tiled_f32_kernel(api, oracle, ocw, kind):
+    """16-bit DN (Landsat-8-like: f32 products round, T1) and arbitrary float imagery take the register-tiled f32 kernel
+    for all four CLI chip sizes.  f64 sums are not exact there, so the summation order shows in the last bits:
+    north_star tolerance |d(u,v)| <= 1e-4 px, identical invalid mask; peak NCC within 1e-6."""
+    c = synth.make_small(seed=700 + ocw, shift=(3, -2), angle_deg=40.0, ocw=ocw, h=300, w=320, dimx=7, dimy=6, null_frac=0.04,
+                         noise_dn=2, margin=ocw + 40, bits=16 if kind == "16bit" else 8)
+    i0, i1 = c.i0, c.i1
+    if kind == "float":
+        rng = np.random.default_rng(ocw)
+        i0 = (i0 * np.float32(0.731) + np.where(i0 > 0, rng.random(i0.shape, dtype=np.float32), 0)).astype(np.float32)
+        i1 = (i1 * np.float32(0.731) + np.where(i1 > 0, rng.random(i1.shape, dtype=np.float32), 0)).astype(np.float32)
+    H, W = i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+    want = oracle.match(i0, i1, c.xyuvav, c.offset, off, uv, ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(i0, i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+        assert ctx.last_path() == "f32_tiled"
+        ctx.set_path("general")
+        gen = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+    for name, g in (("tiled", got), ("general", gen)):
+        assert np.array_equal(np.isnan(g), np.isnan(want)), name
+        assert np.nanmax(np.abs(g[:, :2] - want[:, :2])) <= 1e-4, name
+        assert np.nanmax(np.abs(g[:, 2] - want[:, 2])) <= 1e-6, name
     assert (got[:, 2] > -2.5).mean() > 0.5
