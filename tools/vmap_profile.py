@@ -12,7 +12,10 @@ sys.path.insert(0, ROOT)
 from mimc3_amd import api, synth  # noqa: E402
 
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C2"
-c = synth.make_case("C4" if cfg == "C4s" else cfg)
+c = synth.make_case("C4" if cfg == "C4s" else ("C2" if cfg == "C2x16" else cfg))
+if cfg == "C2x16":     # 16-bit-like DN (Landsat 8): the f32 kernels
+    c = synth.make_case("C2")
+    c.i0[:] = c.i0 * 200; c.i1[:] = c.i1 * 200
 if cfg == "C4s":      # C4's grid and image size with a 4 px shift: C4's own 12 px shift is beyond the CP stage's +-10 px pivots
     c.i0[:], c.i1[:] = synth.make_pair(c.i0.shape[0], c.i0.shape[1], (4, -4), seed=20260104, noise_dn=2, null_frac=0.02)
 xy = c.xyuvav.copy()
