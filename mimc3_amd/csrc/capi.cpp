@@ -274,8 +274,18 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
     const int reach_u = max_abs_piv_u + (off_u < 0 ? -off_u : off_u), reach_v = max_abs_piv_v + (off_v < 0 ? -off_v : off_v);
     hipError_t e;
-    const bool want_u8 = c->path_mode == 0 && c->u8_ok && mimc3::match_u8_supported(ocw, reach_u, reach_v);
-    bool want_u16 = !want_u8 && (c->path_mode == 0 || c->path_mode == 3) && mimc3::match_u8_supported(ocw, reach_u, reach_v);
+    // a tiled kernel is only chosen when the launch's largest window fits its LDS carve (a long corridor on a big chip
+    // does not: 4 B/px at ocw 40 stops fitting at |last pivot| ~47 px); what does not fit takes the next policy down
+    // to the general kernel, which can read the window from L2 -- the reference handles every such input
+    typedef hipError_t (*px_launcher)(mimc3::MatchU8Args, int, int, int, hipStream_t);
+    auto fits = [&](px_launcher fn) {
+        mimc3::MatchU8Args probe{};
+        probe.ocw = ocw; probe.dry_run = 1;
+        return fn(probe, max_abs_piv_u, max_abs_piv_v, max_npiv, nullptr) == hipSuccess;
+    };
+    const bool px_ok = mimc3::match_u8_supported(ocw, reach_u, reach_v);
+    const bool want_u8 = c->path_mode == 0 && c->u8_ok && px_ok && fits(mimc3::launch_match_u8);
+    bool want_u16 = !want_u8 && (c->path_mode == 0 || c->path_mode == 3) && px_ok && fits(mimc3::launch_match_u16);
     if (want_u16 && !c->u16_ok) {
         if (c->u8_ok && c->path_mode == 3 && !c->hpl_valid) {  // tests: 8-bit pairs are scaled integers too (shift 0)
             const size_t hb = sizeof(unsigned short) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
@@ -290,7 +300,8 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         }
         want_u16 = c->u8_ok && c->path_mode == 3;
     }
-    const bool want_f32x = !want_u8 && !want_u16 && c->path_mode != 1 && mimc3::match_f32x_supported(ocw, reach_u, reach_v);
+    const bool want_f32x = !want_u8 && !want_u16 && c->path_mode != 1 && mimc3::match_f32x_supported(ocw, reach_u, reach_v) &&
+                           fits(mimc3::launch_match_f32x);
     if (want_u8 || want_u16 || want_f32x) {
         mimc3::MatchU8Args u{};
         u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W; u.thr = a.thr;

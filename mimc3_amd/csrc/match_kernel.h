@@ -52,6 +52,8 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t cache_cap, map_u16;     // NCC cache slots per point; cell->slot map element width
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off
+    int32_t dry_run;                // launcher only: compute the LDS carve and return hipSuccess / hipErrorInvalidValue (does not fit
+                                    // 160 KB) without launching -- the C ABI asks this before it commits to a kernel policy
 };
 
 // f32 image -> zero-bordered u8 plane (plane must be pre-zeroed); *d_flag is set to 1 if any pixel

@@ -23,6 +23,7 @@
 // `visited` (LDS bytes) mirrors "cmap >= -1.0" of the reference: cells that were only evaluated
 // speculatively but never scanned still read as -2.0 in the final fit (T3, observable laziness).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "match_kernel.h"
 
@@ -364,14 +365,16 @@ static size_t lds_layout(MatchArgs &a, int ocw, int max_abs_u, int max_abs_v, in
 hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_done{0ull};   // the attribute is per device: bit d = device d configured (contexts of several devices may launch from several host threads)
     const size_t kLdsCap = 160 * 1024;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
-        attr_set = true;
+        if (dev < 64) attr_done.fetch_or(1ull << dev);
     }
     bool win_lds = true;
     size_t bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, true);

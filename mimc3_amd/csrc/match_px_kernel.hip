@@ -21,6 +21,7 @@
 //   * per-cell modes FAST / CHIPNULL / GENERAL (null handling), slot-mapped NCC cache, speculative
 //     parallel climb + exact replay of the reference's sequential hill climb (:691-753): see DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -1086,16 +1087,19 @@ hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, 
 }
 
 // ---- launcher -------------------------------------------------------------------------------------
+// LDS carve of one configuration for the launch's largest window; returns the bytes (fills `a` when given)
 template <class C>
-static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_npiv)
 {
+    MatchU8Args tmp{};
+    MatchU8Args &r = a ? *a : tmp;
     const int Dx2 = 2 * (max_abs_u + C::OCW + 2) + 1, Dy2 = 2 * (max_abs_v + C::OCW + 2) + 1;
     const int cells = (Dx2 - 2 * C::OCW + 1) * (Dy2 - 2 * C::OCW + 1);
     // pitch (dwords): written dwords + one zero dword, and the right-most cell's sliding read-ahead
     const int csx = Dx2 - 2 * C::OCW + 1;
     constexpr int G = C::P::G, LG = C::P::LOG2G;
     const int pw_a = ((G - 1 + (Dx2 - 1) + G - 1) >> LG) + 1, pw_b = ((G - 1 + csx - 2) >> LG) + C::GPR + 1;
-    a.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
+    r.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
     // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
     static const int slack_env = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 0;   // tests shrink it to force the overflow path
@@ -1103,25 +1107,42 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     int cap = 9 * max_npiv + slack;
     if (cap > cells) cap = cells;
     if (cap < 16) cap = 16;
-    a.cache_cap = cap;
-    a.map_u16 = cap > 255 ? 1 : 0;
-    a.lds_list_cap = cap + 16;
-    size_t off = (size_t)a.lds_pw * Dy2;
-    off = (off + 15) & ~(size_t)15; a.lds_off_val = (int)off; off += (size_t)cells * (a.map_u16 ? 2 : 1);
-    off = (off + 15) & ~(size_t)15; a.lds_off_ncc = (int)off; off += 4 * (size_t)cap;
-    off = (off + 15) & ~(size_t)15; a.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
-    off = (off + 15) & ~(size_t)15; a.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
-    off = (off + 15) & ~(size_t)15; a.lds_off_list = (int)off; off += 4 * (size_t)a.lds_list_cap;
-    off = (off + 15) & ~(size_t)15; a.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 64;
-    off = (off + 15) & ~(size_t)15; a.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
+    r.cache_cap = cap;
+    r.map_u16 = cap > 255 ? 1 : 0;
+    r.lds_list_cap = cap + 16;
+    size_t off = (size_t)r.lds_pw * Dy2;
+    off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += (size_t)cells * (r.map_u16 ? 2 : 1);
+    off = (off + 15) & ~(size_t)15; r.lds_off_ncc = (int)off; off += 4 * (size_t)cap;
+    off = (off + 15) & ~(size_t)15; r.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
+    off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
+    off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 4 * (size_t)r.lds_list_cap;
+    off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 64;
+    off = (off + 15) & ~(size_t)15; r.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
     off = (off + 15) & ~(size_t)15;
-    if (off > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_px<C>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    return off;
+}
+static constexpr size_t kLdsCapBytes = 160 * 1024;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: remember which devices have it for this instantiation
+template <class C>
+static void px_set_lds_attr()
+{
+    static std::atomic<unsigned long long> done{0ull};   // bit d = device d configured (several devices may launch from several host threads)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 64 && ((done.load() >> dev) & 1ull)) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_px<C>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCapBytes);
+    if (dev < 64) done.fetch_or(1ull << dev);
+}
+
+template <class C>
+static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+{
+    const size_t off = px_layout<C>(&a, max_abs_u, max_abs_v, max_npiv);
+    if (off > kLdsCapBytes) return hipErrorInvalidValue;   // nothing was launched: callers probe with dry_run and take the general kernel instead
+    if (a.dry_run) return hipSuccess;
+    px_set_lds_attr<C>();
     const unsigned nb = (unsigned)((a.N + 7) & ~7);
     static const int dbg = getenv("MIMC3_U8_DEBUG_STOP") ? atoi(getenv("MIMC3_U8_DEBUG_STOP")) : 0;
     // speculative 3x3 blocks requested ahead along a straight move: pays on the small chips (cheap evaluations, idle
@@ -1164,7 +1185,7 @@ bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
 
 hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
-    if (a.N <= 0) return hipSuccess;
+    if (a.N <= 0 && !a.dry_run) return hipSuccess;
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
@@ -1177,7 +1198,7 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 
 hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
-    if (a.N <= 0) return hipSuccess;
+    if (a.N <= 0 && !a.dry_run) return hipSuccess;
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
@@ -1191,7 +1212,7 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
 
 hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
-    if (a.N <= 0) return hipSuccess;
+    if (a.N <= 0 && !a.dry_run) return hipSuccess;
     switch (a.ocw) {       // the u8 configurations, fed from u16 planes through per-point offsets
     case 7: return launch_cfg<PxCfg<PxU8o, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
@@ -1243,7 +1264,7 @@ bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v)
 
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
-    if (a.N <= 0) return hipSuccess;
+    if (a.N <= 0 && !a.dry_run) return hipSuccess;
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxU8, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);

@@ -306,3 +306,54 @@ def test_16bit_and_float_imagery_on_the_tiled_f32_kernel(api, oracle, ocw, kind)
         # integer DN: every f32 product is an integer (rounded to 24 significant bits when it exceeds them) and the f64
         # sums stay below 2^53, i.e. exact in ANY order -- 16-bit imagery is bit-identical as well
         assert_bits_equal(got, want, "tiled, 16-bit"); assert_bits_equal(gen, want, "general, 16-bit")
+
+
+@pytest.mark.parametrize("mode", ["auto", "u16", "f32", "general"])
+@pytest.mark.parametrize("reach", [60, 100])
+def test_long_corridor_big_chip_falls_back_when_lds_is_short(api, oracle, reach, mode):
+    """A fast a-priori on the largest CLI chip (ocw 40): the window (2*(reach+42)+1)^2 outgrows the 160 KB LDS carve of
+    the tiled f32 kernel at reach ~47, of the u16 kernel at ~70 and of the u8 kernel at ~90 (window + the cell map of
+    the 2*reach+6 wide compact grid).  Such launches take the next policy down to the
+    general kernel (which reads the window through L2) -- the reference handles these inputs, so must the library."""
+    speed = {60: 14100.0, 100: 23600.0}[reach]
+    size = 2 * (reach + 42) + 140
+    c = synth.make_small(seed=800 + reach, shift=(5, -5), angle_deg=45.0, ocw=40, speed=speed, h=size, w=size + 8, dimx=3, dimy=3,
+                         margin=reach + 60, noise_dn=2, null_frac=0.02)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    mu = int(np.abs(uv[off[1:] - 1]).max())
+    assert mu >= reach - 2, mu
+    want = oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        ctx.set_path(mode)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        path = ctx.last_path()
+        sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
+    expect = {(60, "auto"): "u8_exact", (60, "u16"): "u16_scaled", (60, "f32"): "general_f32", (60, "general"): "general_f32",
+              (100, "auto"): "general_f32", (100, "u16"): "general_f32", (100, "f32"): "general_f32", (100, "general"): "general_f32"}
+    assert path == expect[(reach, mode)]
+    assert_bits_equal(got, want)
+    assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
+
+
+def test_long_corridor_16bit_and_float_pairs(api, oracle):
+    """the same corridor on imagery that has no integer kernel (16-bit DN, floats): previously 'match kernel launch:
+    invalid argument', now the general kernel"""
+    c = synth.make_small(seed=861, shift=(5, -5), angle_deg=45.0, ocw=40, speed=14100.0, h=344, w=352, dimx=3, dimy=3,
+                         margin=120, noise_dn=300, null_frac=0.02, bits=16)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    rng = np.random.default_rng(3)
+    f0 = (c.i0 * np.float32(0.0031) + np.where(c.i0 > 0, rng.random(c.i0.shape, dtype=np.float32), 0)).astype(np.float32)
+    f1 = (c.i1 * np.float32(0.0031) + np.where(c.i1 > 0, rng.random(c.i1.shape, dtype=np.float32), 0)).astype(np.float32)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert ctx.last_path() == "general_f32"
+        assert_bits_equal(got, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw), "16-bit")
+        ctx.set_images(f0, f1)
+        gf = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert ctx.last_path() == "general_f32"
+    wf = oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, c.ocw)
+    assert np.array_equal(np.isnan(gf), np.isnan(wf)) and np.nanmax(np.abs(gf[:, :2] - wf[:, :2])) <= 1e-4
