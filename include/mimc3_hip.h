@@ -22,6 +22,7 @@
 #ifndef MIMC3_HIP_H
 #define MIMC3_HIP_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -44,6 +45,14 @@ const char *mimc3_last_error(void);
 
 /* Upload a host image pair (replaces the reference holding GMA_float *i0,*i1 in host RAM). */
 int mimc3_ctx_set_images(mimc3_ctx *ctx, const float *i0, const float *i1, int32_t H, int32_t W);
+/* The same from the RAW DN the TIFF holds (the widening to float32 of GMA_float_load_tiff, GMA.c:288-310, then runs on
+ * the device): 1 or 2 bytes per pixel cross PCIe instead of 4, and 8-bit DN lands directly in the exact-integer
+ * kernel's planes.  Results are identical to widening on the host and calling mimc3_ctx_set_images.
+ * Any host pointer works; memory from mimc3_host_alloc (pinned) is DMA'd without the staging copy. */
+int mimc3_ctx_set_images_u8(mimc3_ctx *ctx, const uint8_t *i0, const uint8_t *i1, int32_t H, int32_t W);
+int mimc3_ctx_set_images_u16(mimc3_ctx *ctx, const uint16_t *i0, const uint16_t *i1, int32_t H, int32_t W);
+void *mimc3_host_alloc(size_t bytes);     /* pinned host memory (NULL on failure); read TIFF scanlines straight into it */
+void  mimc3_host_free(void *p);
 /* Adopt device-resident images (no copy; caller keeps ownership, must outlive the context use). */
 int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i1, int32_t H, int32_t W);
 

@@ -37,6 +37,12 @@ _lib.mimc3_ctx_destroy.argtypes = [_vp]
 _lib.mimc3_ctx_destroy.restype = None
 _lib.mimc3_ctx_set_images.argtypes = [_vp, _f32p, _f32p, C.c_int32, C.c_int32]
 _lib.mimc3_ctx_set_images_dev.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_ctx_set_images_u8.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_ctx_set_images_u16.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_host_alloc.argtypes = [C.c_size_t]
+_lib.mimc3_host_alloc.restype = _vp
+_lib.mimc3_host_free.argtypes = [_vp]
+_lib.mimc3_host_free.restype = None
 _lib.mimc3_get_uv_pivot.argtypes = [_f64p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, _i64p, _vp, C.c_int64, C.POINTER(C.c_int64)]
 _lib.mimc3_match_ncc_dlc.argtypes = [_vp, _f64p, C.c_int32, _i32p, _i32p, _i64p, C.c_int32, C.c_int32, _f32p]
@@ -159,6 +165,35 @@ def get_ruv_neighbor(xyuvav, dimx, dimy, meter_per_spacing, radius, cap=4096):
     return np.ascontiguousarray(ruv[:nn.value])
 
 
+class _Pinned:
+    def __init__(self, nbytes):
+        self.p = _lib.mimc3_host_alloc(nbytes)
+        if not self.p:
+            raise MemoryError("mimc3_host_alloc failed")
+        self.buf = (C.c_char * nbytes).from_address(self.p)
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            _lib.mimc3_host_free(self.p)
+            self.p = None
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in pinned host memory (mimc3_host_alloc): host<->device copies of it need no staging."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    pin = _Pinned(max(n, 1))
+    a = np.frombuffer(pin.buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    a.flags.writeable = True
+    _PIN_KEEP[id(a)] = pin
+    import weakref
+    weakref.finalize(a, _PIN_KEEP.pop, id(a), None)
+    return a
+
+
+_PIN_KEEP = {}
+
+
 # ---------------------------------------------------------------------------------------------
 # device context
 # ---------------------------------------------------------------------------------------------
@@ -196,6 +231,15 @@ class Context:
         assert i0.shape == i1.shape and i0.ndim == 2
         self.H, self.W = i0.shape
         _check(_lib.mimc3_ctx_set_images(self._h, i0, i1, self.H, self.W), "ctx_set_images")
+
+    def set_images_raw(self, i0, i1):
+        """The pair as the TIFF holds it (uint8 or uint16 arrays): raw DN crosses PCIe, the widening to float32 of
+        GMA_float_load_tiff (GMA.c:288-310) runs on the device.  Arrays from pinned_empty() are DMA'd without staging."""
+        assert i0.shape == i1.shape and i0.ndim == 2 and i0.dtype == i1.dtype and i0.dtype in (np.uint8, np.uint16)
+        i0 = np.ascontiguousarray(i0); i1 = np.ascontiguousarray(i1)
+        self.H, self.W = i0.shape
+        fn = _lib.mimc3_ctx_set_images_u8 if i0.dtype == np.uint8 else _lib.mimc3_ctx_set_images_u16
+        _check(fn(self._h, i0.ctypes.data, i1.ctypes.data, self.H, self.W), "ctx_set_images_raw")
 
     def set_images_dev(self, d_i0, d_i1, H, W, keep=None):
         """d_i0/d_i1: integer device addresses (e.g. torch tensor.data_ptr()); keep = objects to hold."""

@@ -83,7 +83,90 @@ struct mimc3_ctx {
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // host -> device staging: two pinned chunks that a pageable source is pipelined through (a pinned source is DMA'd directly)
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
+    DevBuf raw_dn;                      // raw 8/16-bit DN as uploaded (mimc3_ctx_set_images_u8/_u16), widened on the device
 };
+
+static constexpr size_t kPinChunk = 4u << 20;
+
+// Copy `bytes` from host memory to the device on the context's stream.  Pinned / registered sources go in one DMA;
+// pageable ones are pipelined through two pinned 4 MiB chunks (host memcpy of chunk k+1 overlaps the DMA of chunk k),
+// which is ~10x the rate hipMemcpy reaches from pageable memory on this platform.  Returns after enqueueing (pinned) or
+// after the last chunk was handed to the DMA engine (pageable); the caller synchronises the stream.
+static int h2d_copy(mimc3_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    (void)hipGetLastError();                                   // "not a HIP pointer" is the expected answer for pageable memory
+    if (bytes < (256u << 10)) {                               // small: the runtime's own staging is fine
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!c->pin[k]) HIP_TRY(hipHostMalloc(&c->pin[k], kPinChunk, hipHostMallocDefault));
+        if (!c->ev_pin[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_pin[k], hipEventDisableTiming));
+    }
+    size_t off = 0;
+    for (int k = 0; off < bytes; k ^= 1) {
+        const size_t n = bytes - off < kPinChunk ? bytes - off : kPinChunk;
+        HIP_TRY(hipEventSynchronize(c->ev_pin[k]));             // the DMA that last read this chunk has finished
+        std::memcpy(c->pin[k], static_cast<const char *>(src) + off, n);
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst) + off, c->pin[k], n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_pin[k], c->stream));
+        off += n;
+    }
+    return 0;
+}
+// Device -> host, synchronous (returns with the bytes in `dst`): through the pinned chunks when `dst` is pageable.
+static int d2h_copy(mimc3_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    hipPointerAttribute_t at{};
+    const bool pinned = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    if (pinned || bytes < (256u << 10)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!c->pin[k]) HIP_TRY(hipHostMalloc(&c->pin[k], kPinChunk, hipHostMallocDefault));
+        if (!c->ev_pin[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_pin[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));                    // nothing else may be using the chunks
+    size_t off = 0, prev_off = 0, prev_n = 0;
+    int k = 0;
+    while (off < bytes || prev_n) {
+        size_t n = 0;
+        if (off < bytes) {
+            n = bytes - off < kPinChunk ? bytes - off : kPinChunk;
+            HIP_TRY(hipMemcpyAsync(c->pin[k], static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_pin[k], c->stream));
+        }
+        if (prev_n) {                                            // drain the previous chunk while this one is in flight
+            HIP_TRY(hipEventSynchronize(c->ev_pin[k ^ 1]));
+            std::memcpy(static_cast<char *>(dst) + prev_off, c->pin[k ^ 1], prev_n);
+        }
+        prev_off = off; prev_n = n; off += n; k ^= 1;
+    }
+    return 0;
+}
+#define RC_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+extern "C" void *mimc3_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void mimc3_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 static float min_dn_threshold()
 {
@@ -127,6 +210,9 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
     c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
+    c->raw_dn.release(); c->cellws.release();
+    for (auto &pp : c->pin) if (pp) (void)hipHostFree(pp);
+    for (auto &ev : c->ev_pin) if (ev) (void)hipEventDestroy(ev);
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
     for (auto &ev : c->ev_side) if (ev) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -137,13 +223,17 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
 
 // Build the zero-bordered u8 planes and prove (on the device) that both images are 8-bit integral.
 // Runs once per image pair; the CLI then reuses the pair for 8 matcher passes (MIMC_main.c:261-300).
-static int prepare_u8(mimc3_ctx *c)
+static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
 {
     c->u8_ok = false;
     c->fplanes_ok = false;
     const int pad = mimc3::kU8Pad;
     c->Wp = (c->W + 2 * pad + 3) & ~3;
     const size_t bytes = (size_t)(c->H + 2 * pad) * c->Wp;
+    if (planes_built) {                 // raw 8-bit DN was widened straight into the planes (mimc3_ctx_set_images_u8)
+        c->u8_ok = true; c->u16_ok = false; c->hpl_valid = false; c->u8o_ok = false;
+        return 0;
+    }
     HIP_TRY(c->pl0.reserve(bytes));
     HIP_TRY(c->pl1.reserve(bytes));
     HIP_TRY(c->flag.reserve(sizeof(int)));
@@ -217,13 +307,61 @@ extern "C" int mimc3_ctx_set_images(mimc3_ctx *c, const float *i0, const float *
     const size_t bytes = sizeof(float) * (size_t)H * W;
     HIP_TRY(c->own_i0.reserve(bytes));
     HIP_TRY(c->own_i1.reserve(bytes));
-    HIP_TRY(hipMemcpyAsync(c->own_i0.p, i0, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->own_i1.p, i1, bytes, hipMemcpyHostToDevice, c->stream));
+    RC_TRY(h2d_copy(c, c->own_i0.p, i0, bytes));
+    RC_TRY(h2d_copy(c, c->own_i1.p, i1, bytes));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->d_i0 = c->raw_i0 = static_cast<const float *>(c->own_i0.p);
     c->d_i1 = c->raw_i1 = static_cast<const float *>(c->own_i1.p);
     c->H = H; c->W = W; c->filt_live = false;
     return prepare_u8(c);
+}
+
+// Raw DN entry points: what the TIFF holds crosses PCIe (1 or 2 bytes per pixel instead of 4) and the widening to f32
+// of GMA_float_load_tiff (GMA.c:288-310) runs on the device.  8-bit DN also lands directly in the u8 planes.
+extern "C" int mimc3_ctx_set_images_u8(mimc3_ctx *c, const uint8_t *i0, const uint8_t *i1, int32_t H, int32_t W)
+{
+    if (!c || !i0 || !i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_u8: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)H * W, half = (npx + 255) & ~(size_t)255;
+    HIP_TRY(c->own_i0.reserve(sizeof(float) * npx));
+    HIP_TRY(c->own_i1.reserve(sizeof(float) * npx));
+    HIP_TRY(c->raw_dn.reserve(2 * half));
+    unsigned char *r0 = static_cast<unsigned char *>(c->raw_dn.p), *r1 = r0 + half;
+    RC_TRY(h2d_copy(c, r0, i0, npx));
+    RC_TRY(h2d_copy(c, r1, i1, npx));
+    const int pad = mimc3::kU8Pad;
+    c->H = H; c->W = W; c->filt_live = false;
+    c->Wp = (W + 2 * pad + 3) & ~3;
+    const size_t pbytes = (size_t)(H + 2 * pad) * c->Wp;
+    HIP_TRY(c->pl0.reserve(pbytes));
+    HIP_TRY(c->pl1.reserve(pbytes));
+    HIP_TRY(hipMemsetAsync(c->pl0.p, 0, pbytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->pl1.p, 0, pbytes, c->stream));
+    HIP_TRY(mimc3::launch_widen_u8(r0, H, W, static_cast<float *>(c->own_i0.p), static_cast<unsigned char *>(c->pl0.p), c->Wp, pad, c->stream));
+    HIP_TRY(mimc3::launch_widen_u8(r1, H, W, static_cast<float *>(c->own_i1.p), static_cast<unsigned char *>(c->pl1.p), c->Wp, pad, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->d_i0 = c->raw_i0 = static_cast<const float *>(c->own_i0.p);
+    c->d_i1 = c->raw_i1 = static_cast<const float *>(c->own_i1.p);
+    return prepare_u8(c, true);
+}
+
+extern "C" int mimc3_ctx_set_images_u16(mimc3_ctx *c, const uint16_t *i0, const uint16_t *i1, int32_t H, int32_t W)
+{
+    if (!c || !i0 || !i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_u16: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)H * W, half = (2 * npx + 255) & ~(size_t)255;
+    HIP_TRY(c->own_i0.reserve(sizeof(float) * npx));
+    HIP_TRY(c->own_i1.reserve(sizeof(float) * npx));
+    HIP_TRY(c->raw_dn.reserve(2 * half));
+    char *r0 = static_cast<char *>(c->raw_dn.p), *r1 = r0 + half;
+    RC_TRY(h2d_copy(c, r0, i0, 2 * npx));
+    RC_TRY(h2d_copy(c, r1, i1, 2 * npx));
+    HIP_TRY(mimc3::launch_widen_u16(reinterpret_cast<const unsigned short *>(r0), npx, static_cast<float *>(c->own_i0.p), c->stream));
+    HIP_TRY(mimc3::launch_widen_u16(reinterpret_cast<const unsigned short *>(r1), npx, static_cast<float *>(c->own_i1.p), c->stream));
+    c->d_i0 = c->raw_i0 = static_cast<const float *>(c->own_i0.p);
+    c->d_i1 = c->raw_i1 = static_cast<const float *>(c->own_i1.p);
+    c->H = H; c->W = W; c->filt_live = false;
+    return prepare_u8(c);              // 16-bit files may still hold 8- or 12-bit DN: classified on the device as usual
 }
 
 extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
@@ -271,6 +409,13 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     a.thr = min_dn_threshold();
     a.out = d_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {   // the general kernel (the last resort of every policy) keeps the cell grid in a global workspace when it outgrows LDS
+        const size_t ws = mimc3::match_f32_workspace_bytes(ocw, max_abs_piv_u, max_abs_piv_v, max_npiv, 0);
+        if (ws) {
+            HIP_TRY(c->cellws.reserve(ws));
+            a.cell_ws = static_cast<unsigned char *>(c->cellws.p); a.cell_ws_bytes = c->cellws.cap;
+        }
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
     const int reach_u = max_abs_piv_u + (off_u < 0 ? -off_u : off_u), reach_v = max_abs_piv_v + (off_v < 0 ? -off_v : off_v);
     hipError_t e;
@@ -388,16 +533,14 @@ extern "C" int mimc3_match_ncc_dlc(mimc3_ctx *c, const double *xyuvav, int32_t N
     HIP_TRY(c->puv.reserve(sizeof(int32_t) * 2 * P));
     HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + 1)));
     HIP_TRY(c->out.reserve(sizeof(float) * 3 * (size_t)N));
-    HIP_TRY(hipMemcpyAsync(c->xy.p, xyuvav, sizeof(double) * 6 * (size_t)N, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->puv.p, piv_uv, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->poff.p, piv_off, sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, c->stream));
+    RC_TRY(h2d_copy(c, c->xy.p, xyuvav, sizeof(double) * 6 * (size_t)N));
+    RC_TRY(h2d_copy(c, c->puv.p, piv_uv, sizeof(int32_t) * 2 * P));
+    RC_TRY(h2d_copy(c, c->poff.p, piv_off, sizeof(int64_t) * ((size_t)N + 1)));
     rc = mimc3_match_ncc_dlc_dev(c, static_cast<const double *>(c->xy.p), N, offset[0], offset[1],
                                  static_cast<const int32_t *>(c->puv.p), static_cast<const int64_t *>(c->poff.p), mn, mu, mv,
                                  ocw, swap, static_cast<float *>(c->out.p), c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->out.p, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return d2h_copy(c, out, c->out.p, sizeof(float) * 3 * (size_t)N);
 }
 
 // ---------------------------------------------------------------------------------------------

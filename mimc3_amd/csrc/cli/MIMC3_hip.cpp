@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
 #include <unistd.h>
 #include <tiffio.h>
 #include "../../../include/mimc3_hip.h"
@@ -56,28 +57,37 @@ bool timestamp_of(const char *path, char out[15])                               
     return true;
 }
 
-// GMA_float_load_tiff (GMA.c:246-316): scanline reader, bytes per pixel = scanline size / width, 1 -> u8, else u16
-bool load_tiff(const char *path, std::vector<float> &img, int32_t &H, int32_t &W)
+// GMA_float_load_tiff (GMA.c:246-316): scanline reader; bytes per pixel = scanline size / width, 1 -> u8, 2 -> u16.
+// The reference widens to float32 on the host (:288-310); here the RAW DN is kept (scanlines are read straight into
+// the buffer that crosses PCIe) and the widening runs on the device (mimc3_ctx_set_images_u8/_u16).
+// Anything the reference's reader would misread (1/4-bit, multi-sample, 32-bit) is refused instead.
+struct RawImage {
+    std::vector<unsigned char> px;      // H * W * bpp bytes, row-major
+    int32_t H = 0, W = 0, bpp = 0;
+};
+bool load_tiff(const char *path, RawImage &img)
 {
     TIFF *tif = TIFFOpen(path, "r");
     if (!tif) return false;
     uint32_t h = 0, w = 0;
+    uint16_t bits = 0, spp = 1;
     TIFFGetField(tif, TIFFTAG_IMAGELENGTH, &h);
     TIFFGetField(tif, TIFFTAG_IMAGEWIDTH, &w);
+    TIFFGetFieldDefaulted(tif, TIFFTAG_BITSPERSAMPLE, &bits);
+    TIFFGetFieldDefaulted(tif, TIFFTAG_SAMPLESPERPIXEL, &spp);
     const tsize_t scan = TIFFScanlineSize(tif);
-    if (h == 0 || w == 0 || scan <= 0) { TIFFClose(tif); return false; }
-    const int bpp = (int)((uint32_t)scan / w);
-    std::vector<unsigned char> buf((size_t)scan);
-    img.resize((size_t)h * w);
-    for (uint32_t r = 0; r < h; r++) {
-        if (TIFFReadScanline(tif, buf.data(), r, 0) < 0) { TIFFClose(tif); return false; }
-        float *o = img.data() + (size_t)r * w;
-        if (bpp == 1) for (uint32_t c = 0; c < w; c++) o[c] = (float)buf[c];
-        else { const uint16_t *p16 = reinterpret_cast<const uint16_t *>(buf.data()); for (uint32_t c = 0; c < w; c++) o[c] = (float)p16[c]; }
+    const int bpp = bits / 8;
+    if (h == 0 || w == 0 || scan <= 0 || (bits != 8 && bits != 16) || spp != 1 || (size_t)scan != (size_t)w * bpp) {
+        fprintf(stderr, "%s: only single-sample 8- or 16-bit images are supported (bits=%d, samples=%d)\n", path, (int)bits, (int)spp);
+        TIFFClose(tif);
+        return false;
     }
+    img.px.resize((size_t)h * w * bpp);
+    for (uint32_t r = 0; r < h; r++)
+        if (TIFFReadScanline(tif, img.px.data() + (size_t)r * scan, r, 0) < 0) { TIFFClose(tif); return false; }
     TIFFClose(tif);
-    H = (int32_t)h; W = (int32_t)w;
-    printf("Loading TIFF - row=%d, col=%d, bytes per pixel=%d\n", H, (int)scan, bpp);
+    img.H = (int32_t)h; img.W = (int32_t)w; img.bpp = bpp;
+    printf("Loading TIFF - row=%d, col=%d, bytes per pixel=%d\n", img.H, (int)scan, bpp);
     return true;
 }
 
@@ -142,15 +152,36 @@ int main(int argc, char *argv[])
     std::vector<double> xy;
     int32_t N = 0, ncol = 0;
     if (!load_gma_double(argv[3], xy, N, ncol) || ncol != 6) { fprintf(stderr, "cannot read %s as an [N][6] float64 .GMA\n", argv[3]); return 2; }
-    std::vector<float> i0, i1;
-    int32_t H = 0, W = 0, H1 = 0, W1 = 0;
-    if (!load_tiff(argv[1], i0, H, W) || !load_tiff(argv[2], i1, H1, W1)) { fprintf(stderr, "cannot read the TIFF images\n"); return 2; }
-    if (H != H1 || W != W1) { fprintf(stderr, "the two images differ in size\n"); return 2; }
-
+    // the HIP runtime and the device context come up on a second thread while this one decodes the TIFFs
     const char *dev = getenv("MIMC3_HIP_DEVICE");
     mimc3_ctx *ctx = nullptr;
-    if (mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx)) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
-    if (mimc3_ctx_set_images(ctx, i0.data(), i1.data(), H, W)) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
+    int ctx_rc = 0;
+    std::string ctx_err;
+    std::thread ctx_thread([&]() {
+        ctx_rc = mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx);
+        if (ctx_rc) ctx_err = mimc3_last_error();
+    });
+    RawImage i0, i1;
+    const bool tiff_ok = load_tiff(argv[1], i0) && load_tiff(argv[2], i1);
+    ctx_thread.join();
+    if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); if (ctx) mimc3_ctx_destroy(ctx); return 2; }
+    if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); if (ctx) mimc3_ctx_destroy(ctx); return 2; }
+    if (ctx_rc) { fprintf(stderr, "%s\n", ctx_err.c_str()); return 3; }
+    const int32_t H = i0.H, W = i0.W;
+    int rc;
+    if (i0.bpp == 1 && i1.bpp == 1) rc = mimc3_ctx_set_images_u8(ctx, i0.px.data(), i1.px.data(), H, W);
+    else if (i0.bpp == 2 && i1.bpp == 2)
+        rc = mimc3_ctx_set_images_u16(ctx, reinterpret_cast<const uint16_t *>(i0.px.data()), reinterpret_cast<const uint16_t *>(i1.px.data()), H, W);
+    else {                                    // one 8-bit and one 16-bit file: widen on the host like the reference
+        std::vector<float> f0((size_t)H * W), f1((size_t)H * W);
+        auto widen = [&](const RawImage &im, std::vector<float> &f) {
+            if (im.bpp == 1) for (size_t k = 0; k < f.size(); k++) f[k] = (float)im.px[k];
+            else { const uint16_t *q = reinterpret_cast<const uint16_t *>(im.px.data()); for (size_t k = 0; k < f.size(); k++) f[k] = (float)q[k]; }
+        };
+        widen(i0, f0); widen(i1, f1);
+        rc = mimc3_ctx_set_images(ctx, f0.data(), f1.data(), H, W);
+    }
+    if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
 
     std::vector<float> vx(N), vy(N), ex(N), ey(N), qual(N);
     std::vector<uint8_t> flag(N);

@@ -25,7 +25,13 @@ struct MatchArgs {
     const int32_t *point_count;  // ... whose length is read on the device (nullptr = all N points)
     // LDS carve (floats / pivots), filled by the launcher from the per-launch maxima
     int32_t lds_chip_f, lds_win_f, lds_cell_f, lds_npiv;
+    // global workspace for the compact cell grid when it outgrows LDS (long diagonal corridors): kCellGlobalGrid slices
+    unsigned char *cell_ws;
+    size_t cell_ws_bytes, cell_ws_stride;
+    int32_t cell_ws_cells;
 };
+constexpr int kCellGlobalGrid = 1024;   // persistent workgroups of the workspace mode (4 per CU)
+size_t match_f32_workspace_bytes(int ocw, int max_abs_u, int max_abs_v, int max_npiv, int win_half);
 
 // ---- exact-integer path for 8-bit imagery (match_u8_kernel.hip) -------------------------------
 constexpr int kU8Pad = 256;      // zero border (pixels) around the u8 planes; multiple of 4
@@ -59,6 +65,10 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
 // f32 image -> zero-bordered u8 plane (plane must be pre-zeroed); *d_flag is set to 1 if any pixel
 // is not an integer in [0,255] (then the u8 path must not be used for this image).
 hipError_t launch_prep_u8(const float *img, int H, int W, unsigned char *plane, int Wp, int pad, int *d_flag, hipStream_t s);
+// raw DN as the TIFF holds it -> f32 image (+ the u8 plane for 8-bit DN; plane pre-zeroed): the widening of
+// GMA_float_load_tiff (GMA.c:288-310) done on the device so that only the raw bytes cross PCIe
+hipError_t launch_widen_u8(const unsigned char *raw, int H, int W, float *img, unsigned char *plane, int Wp, int pad, hipStream_t s);
+hipError_t launch_widen_u16(const unsigned short *raw, size_t n, float *img, hipStream_t s);
 // instantiated chip sizes and border reach (|last pivot| + |CP offset| must fit in the border)
 bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v);
 // same kernel family on zero-bordered u16 planes of scaled integers (q = value * 2^shift < 4096): same chip sizes as u8

@@ -100,7 +100,10 @@ __device__ __forceinline__ float eval_cell(const float *chip, const Win<WIN_LDS>
     return (float)(num / den);
 }
 
-template <bool WIN_LDS>
+// CELL_G: the NCC cache and the visited flags of the compact cell grid live in a global workspace slice of this
+// workgroup instead of LDS (a long DIAGONAL corridor: (2|last pivot|+6)^2 cells no longer fit 160 KB).  Workgroup
+// barriers order the accesses exactly as for LDS (all waves of a workgroup share one CU's L1).
+template <bool WIN_LDS, bool CELL_G>
 __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, unsigned char *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,6 +137,11 @@ __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, un
     int32_t *pivs = reinterpret_cast<int32_t *>(val + p.lds_cell_f);   // [npiv][2]
     int32_t *ctl = pivs + 2 * p.lds_npiv;                  // control words, see below
     unsigned char *vis = reinterpret_cast<unsigned char *>(ctl + 16);   // [csy][csx] visited flags
+    if (CELL_G) {
+        unsigned char *ws = p.cell_ws + (size_t)blockIdx.x * p.cell_ws_stride;
+        val = reinterpret_cast<float *>(ws);
+        vis = ws + 4 * (size_t)p.cell_ws_cells;
+    }
     // ctl[0]=bad chip count, ctl[1]=bad window count, ctl[2]=state-machine status, ctl[3]=#pending,
     // ctl[4..12]=pending compact cell ids
 
@@ -322,7 +330,7 @@ __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, un
     }
 }
 
-template <bool WIN_LDS>
+template <bool WIN_LDS, bool CELL_G>
 __global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -331,7 +339,14 @@ __global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
         // a small persistent grid strides over the device-side list
         const int cnt = *p.point_count;
         for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
-            match_point_f32<WIN_LDS>(p, p.point_list[i], smem);
+            match_point_f32<WIN_LDS, CELL_G>(p, p.point_list[i], smem);
+            __syncthreads();
+        }
+        return;
+    }
+    if (CELL_G) {                                   // persistent grid: one workspace slice per workgroup
+        for (int i = blockIdx.x; i < p.N; i += gridDim.x) {
+            match_point_f32<WIN_LDS, CELL_G>(p, i, smem);
             __syncthreads();
         }
         return;
@@ -344,22 +359,33 @@ __global__ __launch_bounds__(kMatchThreads) void match_ncc_dlc_f32(MatchArgs p)
         if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
     }
     if (gidx >= p.N) return;
-    match_point_f32<WIN_LDS>(p, gidx, smem);
+    match_point_f32<WIN_LDS, CELL_G>(p, gidx, smem);
 }
 
 // ---- host-side launcher --------------------------------------------------------------------------
-static size_t lds_layout(MatchArgs &a, int ocw, int max_abs_u, int max_abs_v, int max_npiv, bool win_lds)
+static size_t lds_layout(MatchArgs &a, int ocw, int max_abs_u, int max_abs_v, int max_npiv, bool win_lds, bool cell_lds)
 {
     const int cw = 2 * ocw + 1;
-    const int Dx2 = 2 * (max_abs_u + ocw + 2) + 1, Dy2 = 2 * (max_abs_v + ocw + 2) + 1;
+    int Dx2 = 2 * (max_abs_u + ocw + 2) + 1, Dy2 = 2 * (max_abs_v + ocw + 2) + 1;
+    if (a.win_half > 0) Dx2 = Dy2 = 2 * a.win_half + 1;
     const int cells = (Dx2 - 2 * ocw + 1) * (Dy2 - 2 * ocw + 1);
     a.lds_chip_f = (cw * cw + 3) & ~3;
     a.lds_win_f = win_lds ? ((Dx2 * Dy2 + 3) & ~3) : 0;
-    a.lds_cell_f = (cells + 3) & ~3;
+    a.lds_cell_f = cell_lds ? ((cells + 3) & ~3) : 0;
     a.lds_npiv = (max_npiv + 1) & ~1;
+    a.cell_ws_cells = (cells + 3) & ~3;
     size_t bytes = sizeof(float) * ((size_t)a.lds_chip_f + a.lds_win_f + a.lds_cell_f) +
-                   sizeof(int32_t) * (2 * (size_t)a.lds_npiv + 16) + (size_t)((cells + 15) & ~15);
+                   sizeof(int32_t) * (2 * (size_t)a.lds_npiv + 16) + (cell_lds ? (size_t)((cells + 15) & ~15) : 16);
     return bytes;
+}
+
+// bytes of global workspace launch_match_f32 needs for this launch (0 unless the cell grid outgrows LDS)
+size_t match_f32_workspace_bytes(int ocw, int max_abs_u, int max_abs_v, int max_npiv, int win_half)
+{
+    MatchArgs a{};
+    a.win_half = win_half;
+    if (lds_layout(a, ocw, max_abs_u, max_abs_v, max_npiv, false, true) <= 160 * 1024) return 0;
+    return (size_t)kCellGlobalGrid * (5 * (size_t)a.cell_ws_cells + 256);
 }
 
 hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
@@ -370,26 +396,33 @@ hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_n
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 64 || !((attr_done.load() >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_ncc_dlc_f32<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
         if (dev < 64) attr_done.fetch_or(1ull << dev);
     }
-    bool win_lds = true;
-    size_t bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, true);
+    // window and cell grid in LDS -> cell grid in LDS, window through L2 -> both outside LDS (persistent grid + workspace)
+    int mode = 0;
+    size_t bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, true, true);
+    if (bytes > kLdsCap) { mode = 1; bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, false, true); }
     if (bytes > kLdsCap) {
-        win_lds = false;
-        bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, false);
-        if (bytes > kLdsCap) return hipErrorInvalidValue;
+        mode = 2; bytes = lds_layout(a, a.ocw, max_abs_u, max_abs_v, max_npiv, false, false);
+        a.cell_ws_stride = 5 * (size_t)a.cell_ws_cells + 256;
+        if (bytes > kLdsCap || !a.cell_ws || a.cell_ws_bytes < (size_t)kCellGlobalGrid * a.cell_ws_stride) return hipErrorInvalidValue;
     }
     // grid rounded up to a multiple of 8 so the XCD remap is a bijection on [0, 8*per)
     unsigned nb = (unsigned)((a.N + 7) & ~7);
     if (a.point_list) nb = nb < 256u ? nb : 256u;        // list mode: one persistent workgroup per CU (the list is usually empty)
-    if (win_lds)
-        hipLaunchKernelGGL(match_ncc_dlc_f32<true>, dim3(nb), dim3(kMatchThreads), bytes, stream, a);
+    if (mode == 2) nb = nb < (unsigned)kCellGlobalGrid ? nb : (unsigned)kCellGlobalGrid;
+    if (mode == 0)
+        hipLaunchKernelGGL((match_ncc_dlc_f32<true, false>), dim3(nb), dim3(kMatchThreads), bytes, stream, a);
+    else if (mode == 1)
+        hipLaunchKernelGGL((match_ncc_dlc_f32<false, false>), dim3(nb), dim3(kMatchThreads), bytes, stream, a);
     else
-        hipLaunchKernelGGL(match_ncc_dlc_f32<false>, dim3(nb), dim3(kMatchThreads), bytes, stream, a);
+        hipLaunchKernelGGL((match_ncc_dlc_f32<false, true>), dim3(nb), dim3(kMatchThreads), bytes, stream, a);
     return hipGetLastError();
 }
 

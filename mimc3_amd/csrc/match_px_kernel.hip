@@ -1034,6 +1034,40 @@ __global__ void prep_u8_plane(const float *img, int H, int W, unsigned char *pla
     plane[(size_t)(y + pad) * Wp + (x + pad)] = ok ? (unsigned char)r : (unsigned char)0;
 }
 
+// ---- raw 8-bit DN -> f32 image (what GMA_float_load_tiff makes on the host, GMA.c:288-298) + zero-bordered u8 plane,
+//      four pixels per thread.  The pair is 8-bit by construction: nothing to prove.
+__global__ void widen_u8_plane(const unsigned char *__restrict__ raw, int H, int W, float *__restrict__ img,
+                               unsigned char *__restrict__ plane, int Wp, int pad)
+{
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
+    unsigned char *pl = plane + (size_t)(y + pad) * Wp + (x + pad);
+    if (x + 3 < W && (i & 3) == 0) {                     // pad and Wp are multiples of 4: the plane dword is aligned when x is
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(raw + i);
+        *reinterpret_cast<float4 *>(img + i) = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+        *reinterpret_cast<uint32_t *>(pl) = v;
+    } else {
+        for (int k = 0; k < 4 && x + k < W; k++) { img[i + k] = (float)raw[i + k]; pl[k] = raw[i + k]; }
+    }
+}
+// ---- raw 16-bit DN -> f32 image (GMA.c:299-309)
+__global__ void widen_u16_image(const unsigned short *__restrict__ raw, size_t n, float *__restrict__ img)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) img[i] = (float)raw[i];
+}
+hipError_t launch_widen_u8(const unsigned char *raw, int H, int W, float *img, unsigned char *plane, int Wp, int pad, hipStream_t s)
+{
+    dim3 blk(256), grd((W + 1023) / 1024, H);
+    hipLaunchKernelGGL(widen_u8_plane, grd, blk, 0, s, raw, H, W, img, plane, Wp, pad);
+    return hipGetLastError();
+}
+hipError_t launch_widen_u16(const unsigned short *raw, size_t n, float *img, hipStream_t s)
+{
+    hipLaunchKernelGGL(widen_u16_image, dim3(4096), dim3(256), 0, s, raw, n, img);
+    return hipGetLastError();
+}
+
 // ---- f32 image -> zero-bordered u16 plane of q = value * 2^s (PxU16 policy) --------------------------
 // flags bit0: some pixel is not an integer in [0,4095]; bit1: some pixel*8 is not an integer in [0,4095]
 __global__ void detect_scaled_int(const float *img, size_t n, int *flags)
