@@ -259,6 +259,11 @@ int mimc3_negate_pivots_dev(mimc3_ctx *ctx, const int32_t *d_piv_uv, int32_t *d_
 int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *ctx, const int32_t *d_dpf, const float *d_mvn, int32_t N, int32_t Kmax,
                                 float *d_out5, void *stream);
 int mimc3_ctx_image_size(mimc3_ctx *ctx, int32_t *H, int32_t *W);
+int mimc3_ctx_device(mimc3_ctx *ctx);
+/*      device scratch owned by the context: slot 0..15, grows on demand, contents kept until the slot is asked for more
+ *      bytes; freed with the context.  The drivers above the ABI (mimc3_postprocess, mimc3_vmap) keep their working
+ *      buffers here instead of allocating per call.  One stream at a time per context. */
+int mimc3_ctx_workspace(mimc3_ctx *ctx, int32_t slot, size_t bytes, void **d_ptr);
 
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */

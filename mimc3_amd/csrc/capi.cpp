@@ -86,6 +86,7 @@ struct mimc3_ctx {
     // host -> device staging: two pinned chunks that a pageable source is pipelined through (a pinned source is DMA'd directly)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    DevBuf slot[16];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
     DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
     DevBuf raw_dn;                      // raw 8/16-bit DN as uploaded (mimc3_ctx_set_images_u8/_u16), widened on the device
 };
@@ -211,6 +212,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->n1_io.release(); c->n1_work.release();
     c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
     c->raw_dn.release(); c->cellws.release();
+    for (auto &b : c->slot) b.release();
     for (auto &pp : c->pin) if (pp) (void)hipHostFree(pp);
     for (auto &ev : c->ev_pin) if (ev) (void)hipEventDestroy(ev);
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
@@ -1126,6 +1128,17 @@ extern "C" int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *c, const int32_t *d_dpf, c
     if (e != hipSuccess) return mimc3::hip_fail(e, "gather kernel launch");
     return 0;
 }
+
+extern "C" int mimc3_ctx_workspace(mimc3_ctx *c, int32_t slot, size_t bytes, void **d_ptr)
+{
+    if (!c || !d_ptr || slot < 0 || slot >= 16) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_workspace: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->slot[slot].reserve(bytes ? bytes : 1));
+    *d_ptr = c->slot[slot].p;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_device(mimc3_ctx *c) { return c ? c->device : MIMC3_EINVAL; }
 
 extern "C" int mimc3_ctx_image_size(mimc3_ctx *c, int32_t *H, int32_t *W)
 {

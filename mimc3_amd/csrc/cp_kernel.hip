@@ -112,7 +112,33 @@ __global__ __launch_bounds__(256) void negate_i32(const int32_t *__restrict__ in
     if (i < n) out[i] = -in[i];
 }
 
+// multi-GPU re-assembly: the all-gathered per-rank blocks [world][npass][per][3] (rank r's point j = grid point perm[r*per+j],
+// -1 = padding) -> the grid-ordered tensor out [npass][N][3]
+__global__ __launch_bounds__(256) void scatter_blocks(const float *__restrict__ g, const int32_t *__restrict__ perm, int32_t world,
+                                                      int32_t per, int32_t npass, int32_t N, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)world * per) return;
+    const int32_t dst = perm[i];
+    if (dst < 0) return;
+    const int32_t r = (int32_t)(i / per), j = (int32_t)(i - (int64_t)r * per);
+    for (int32_t ps = 0; ps < npass; ps++) {
+        const float *src = g + (((size_t)r * npass + ps) * per + j) * 3;
+        float *o = out + ((size_t)ps * N + dst) * 3;
+        o[0] = src[0]; o[1] = src[1]; o[2] = src[2];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_scatter_blocks(const float *g, const int32_t *perm, int32_t world, int32_t per, int32_t npass, int32_t N, float *out,
+                                 hipStream_t stream)
+{
+    const int64_t n = (int64_t)world * per;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, perm, world, per, npass, N, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_negate_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t stream)
 {

@@ -20,8 +20,18 @@
 #include <cstdlib>
 #include "../../include/mimc3_hip.h"
 #include "host_util.h"
+#include "pipeline_internal.h"
 
 namespace {
+
+// context scratch slots (mimc3_ctx_workspace) used by the drivers in this file and in mgpu.cpp
+enum { kSlotPost = 0, kSlotXy = 1, kSlotPiv = 2, kSlotOut5 = 3, kSlotDp = 4, kSlotXyFull = 5 };
+
+// a typed view of a piece of context scratch
+struct View {
+    void *p = nullptr;
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
 
 struct Buf {
     void *p = nullptr;
@@ -75,19 +85,17 @@ extern "C" int mimc3_postprocess_dev(mimc3_ctx *ctx, const float *d_dp, int32_t 
     int32_t nn1 = 0, nn2 = 0;
     RC_TRY(mimc3_get_ruv_neighbor(xyuvav, N, dimx, dimy, meter_per_spacing, radius_dpf1, ruv1.data(), 4096, &nn1));
     RC_TRY(mimc3_get_ruv_neighbor(xyuvav, N, dimx, dimy, meter_per_spacing, radius_ps, ruv2.data(), 4096, &nn2));
-    Buf mvn, ncl, kmax, dpf, dx, dy, r1, r2, w1, w2;
-    HIP_TRY(mvn.alloc(sizeof(float) * 5 * (size_t)N * K));
-    HIP_TRY(ncl.alloc(sizeof(int32_t) * (size_t)N));
-    HIP_TRY(kmax.alloc(sizeof(int32_t)));
-    HIP_TRY(dpf.alloc(sizeof(int32_t) * (size_t)N));
-    HIP_TRY(dx.alloc(sizeof(float) * (size_t)N));
-    HIP_TRY(dy.alloc(sizeof(float) * (size_t)N));
-    HIP_TRY(r1.alloc(8 * (size_t)(nn1 > 0 ? nn1 : 1)));
-    HIP_TRY(r2.alloc(8 * (size_t)(nn2 > 0 ? nn2 : 1)));
-    HIP_TRY(w1.alloc((size_t)mimc3_dpf1_workspace_bytes(N)));
-    HIP_TRY(w2.alloc((size_t)mimc3_qm_workspace_bytes(N, qm_max_sweeps)));
-    HIP_TRY(hipMemcpyAsync(r1.p, ruv1.data(), 8 * (size_t)nn1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r2.p, ruv2.data(), 8 * (size_t)nn2, hipMemcpyHostToDevice, s));
+    // working buffers live in ONE context-owned scratch slot, carved here: no allocation after the first call
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_mvn = al(sizeof(float) * 5 * (size_t)N * K), b_n = al(sizeof(int32_t) * (size_t)N), b_r1 = al(8 * (size_t)(nn1 > 0 ? nn1 : 1)),
+                 b_r2 = al(8 * (size_t)(nn2 > 0 ? nn2 : 1)), b_w1 = al((size_t)mimc3_dpf1_workspace_bytes(N)),
+                 b_w2 = al((size_t)mimc3_qm_workspace_bytes(N, qm_max_sweeps));
+    void *base = nullptr;
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotPost, b_mvn + 4 * b_n + 256 + b_r1 + b_r2 + b_w1 + b_w2, &base));
+    char *cur = static_cast<char *>(base);
+    auto take = [&](size_t b) { View v{cur}; cur += b; return v; };
+    View mvn = take(b_mvn), ncl = take(b_n), kmax = take(256), dpf = take(b_n), dx = take(b_n), dy = take(b_n), r1 = take(b_r1),
+         r2 = take(b_r2), w1 = take(b_w1), w2 = take(b_w2);
     RC_TRY(mimc3_cluster_candidates_dev(ctx, d_dp, ndp, N, K, mvn.as<float>(), ncl.as<int32_t>(), kmax.as<int32_t>(), s));   // :904
     RC_TRY(mimc3_get_dpf0_dev(ctx, mvn.as<float>(), ncl.as<int32_t>(), N, K, 0.6f, dpf.as<int32_t>(), s));                    // :912
     int32_t sweeps = 0;
@@ -96,7 +104,7 @@ extern "C" int mimc3_postprocess_dev(mimc3_ctx *ctx, const float *d_dp, int32_t 
     RC_TRY(mimc3_qm_pseudosmooth_dev(ctx, dimy, dimx, dpf.as<int32_t>(), dx.as<float>(), dy.as<float>(), r2.as<int32_t>(), nn2,
                                      mvn.as<float>(), K, ncl.as<int32_t>(), d_xyuvav, qm_max_sweeps, w2.p, nullptr, s));        // :933
     RC_TRY(mimc3_dpf_to_vxyexyqual_dev(ctx, dpf.as<int32_t>(), mvn.as<float>(), N, K, d_out5, s));                             // :937-970
-    HIP_TRY(hipStreamSynchronize(s));       // the buffers above are freed on return
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -120,7 +128,7 @@ extern "C" int mimc3_postprocess(mimc3_ctx *ctx, const float *dp, int32_t ndp, c
     return 0;
 }
 
-namespace {
+namespace mimc3 {
 
 // grid geometry (MIMC_main.c:209-223)
 int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
@@ -136,7 +144,114 @@ int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
     return 0;
 }
 
-}  // namespace
+HostPivots::~HostPivots() { if (uv) (void)hipHostFree(uv); }
+
+// pivots of the four chip sizes (:264, :316) for the points xs[0..ns): host geometry (libm-exact, threaded) that depends
+// on nothing the CP stage produces; payload in pinned memory.  Safe to call from a worker thread (`device` = the device
+// whose context will upload them); the error text is returned because mimc3_last_error() is thread-local.
+int vmap_host_pivots(const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W, int device,
+                     HostPivots hp[4], std::string &err)
+{
+    (void)hipSetDevice(device);
+    for (int c = 0; c < 4 && ns > 0; c++) {
+        hp[c].off.resize((size_t)ns + 1);
+        int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
+        if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
+            err = "mimc3_vmap: hipHostMalloc for the pivots failed";
+            return MIMC3_ENODEV;
+        }
+        if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
+                                         static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
+        if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
+        if (rc) { err = mimc3_last_error(); return rc; }
+    }
+    return 0;
+}
+
+// CP offset on the whole grid (:240-256): fills res->cp_status / offset_cp and flag_cp
+int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res)
+{
+    mimc3_cp_params cp{};
+    for (int k = 0; k < 4; k++) cp.vec_ocw[k] = p->vec_ocw[k];
+    cp.aw_cre = p->aw_cre; cp.num_cp_max = p->num_cp_max; cp.num_cp_min = p->num_cp_min;
+    cp.ratio_cp = p->ratio_cp; cp.thres_spd_cp = p->thres_spd_cp; cp.seed = p->cp_seed;
+    for (int k = 0; k < 3; k++) { cp.kernel[k] = p->kernel[k]; cp.kdim[k][0] = p->kdim[k][0]; cp.kdim[k][1] = p->kdim[k][1]; }
+    std::memset(flag_cp, 0, (size_t)N);
+    int32_t off[2] = {0, 0}, st = -1;
+    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+    RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
+    res->cp_status = st;
+    if (st >= 0) { res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1]; }
+    return 0;
+}
+
+// The 32 matcher passes (:261-350) for the points xs[0..ns) (any subset of the grid, any order: grid points are independent
+// in the matcher) with the CP offset `off`, into d_dp [32][pass_stride][3] (device, pass-major).  Synchronises the context's stream.
+int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t off[2], HostPivots hp[4], const mimc3_vmap_params *p,
+                    float *d_dp, size_t pass_stride)
+{
+    if (pass_stride < (size_t)ns) pass_stride = (size_t)ns;   // points per pass slot of d_dp (a multi-GPU driver pads its blocks)
+    int32_t H = 0, W = 0;
+    RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
+    StageClock clk;
+    hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
+    // ---- the reference refuses nothing, it reads out of bounds; this library refuses (see mimc3_match_ncc_dlc)
+    int ocw_max = 0;
+    for (int k = 0; k < 4; k++) ocw_max = p->vec_ocw[k] > ocw_max ? p->vec_ocw[k] : ocw_max;
+    for (int32_t i = 0; i < ns; i++) {
+        const int32_t u0 = (int32_t)xs[6 * (size_t)i + 2], v0 = (int32_t)xs[6 * (size_t)i + 3];
+        if (u0 - ocw_max < 0 || u0 + ocw_max >= W || v0 - ocw_max < 0 || v0 + ocw_max >= H)
+            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: a grid point's chip leaves the image (u=" + std::to_string(u0) + ", v=" + std::to_string(v0) + ")");
+    }
+    const size_t n = (size_t)ns;
+    void *d_xy = nullptr;
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotXy, 48 * n, &d_xy));
+    HIP_TRY(hipMemcpyAsync(d_xy, xs, 48 * n, hipMemcpyHostToDevice, s));
+
+    // ---- pivots: forward and negated (:272-279) copies resident for all four image variants (one scratch slot)
+    struct Piv { int32_t *uv, *uvn; int64_t *off; };
+    Piv piv[4];
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t need = 0;
+    for (int c = 0; c < 4; c++) need += 2 * al(8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1)) + al(8 * (n + 1));
+    void *pbase = nullptr;
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotPiv, need, &pbase));
+    char *cur = static_cast<char *>(pbase);
+    for (int c = 0; c < 4; c++) {
+        const size_t tb = 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1);
+        piv[c].uv = reinterpret_cast<int32_t *>(cur); cur += al(tb);
+        piv[c].uvn = reinterpret_cast<int32_t *>(cur); cur += al(tb);
+        piv[c].off = reinterpret_cast<int64_t *>(cur); cur += al(8 * (n + 1));
+        HIP_TRY(hipMemcpyAsync(piv[c].uv, hp[c].uv, 8 * (size_t)hp[c].total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(piv[c].off, hp[c].off.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+        RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv, piv[c].uvn, hp[c].total, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    clk.mark("pivots: upload", s);
+    // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
+    for (int kk = -1; kk <= 2; kk++) {
+        if (kk >= 0) {
+            RC_TRY(mimc3_ctx_filter_images(ctx, p->kernel[kk], p->kdim[kk][0], p->kdim[kk][1]));
+            clk.mark("filter + planes", s);
+        }
+        for (int c = 0; c < 4; c++) {
+            const int slot = (kk + 1) * 8 + c * 2;
+            float *fw = d_dp + (size_t)slot * pass_stride * 3, *sw = fw + pass_stride * 3;
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, static_cast<const double *>(d_xy), ns, off[0], off[1], piv[c].uv, piv[c].off,
+                                           hp[c].mn, hp[c].mu, hp[c].mv, p->vec_ocw[c], 0, fw, s));
+            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, static_cast<const double *>(d_xy), ns, -off[0], -off[1], piv[c].uvn, piv[c].off,
+                                           hp[c].mn, hp[c].mu, hp[c].mv, p->vec_ocw[c], 1, sw, s));
+            RC_TRY(mimc3_negate_uv_dev(ctx, sw, ns, s));     // :289-293
+        }
+        clk.mark("8 matcher passes", s);
+    }
+    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
+    HIP_TRY(hipStreamSynchronize(s));                       // d_dp is complete
+    clk.mark("back to the raw pair", s);
+    return 0;
+}
+
+}  // namespace mimc3
 
 // CP offset on the whole grid, then the 32 matcher passes for grid points [lo, hi) only (grid points are independent in
 // the matcher: this is the unit a multi-GPU driver shards).  d_dp: device, [32][hi-lo][3] pass-major.
@@ -148,107 +263,27 @@ extern "C" int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N
     int32_t H = 0, W = 0;
     RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
     std::memset(res, 0, sizeof(*res));
-    RC_TRY(vmap_geometry(xyuvav, N, res));
-
-    // ---- CP offset (:240-256)
-    mimc3_cp_params cp{};
-    for (int k = 0; k < 4; k++) cp.vec_ocw[k] = p->vec_ocw[k];
-    cp.aw_cre = p->aw_cre; cp.num_cp_max = p->num_cp_max; cp.num_cp_min = p->num_cp_min;
-    cp.ratio_cp = p->ratio_cp; cp.thres_spd_cp = p->thres_spd_cp; cp.seed = p->cp_seed;
-    for (int k = 0; k < 3; k++) { cp.kernel[k] = p->kernel[k]; cp.kdim[k][0] = p->kdim[k][0]; cp.kdim[k][1] = p->kdim[k][1]; }
-    std::memset(flag_cp, 0, (size_t)N);
-    int32_t off[2] = {0, 0}, st = -1;
+    RC_TRY(mimc3::vmap_geometry(xyuvav, N, res));
     StageClock clk;
     hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
     const int32_t ns = hi - lo;
     const double *xs = xyuvav + 6 * (size_t)lo;
-
-    // ---- pivots per chip size (:264, :316): host geometry (libm-exact, threaded) that depends on nothing the CP stage
-    //      produces, so it runs on a host thread WHILE the device measures the CP offset; results in pinned memory
-    struct HostPiv {
-        std::vector<int64_t> off; void *uv = nullptr; int64_t total = 0; int32_t mn = 0, mu = 0, mv = 0;
-        ~HostPiv() { if (uv) (void)hipHostFree(uv); }
-    };
-    HostPiv hp[4];
+    // the host pivots run on a host thread WHILE the device measures the CP offset
+    mimc3::HostPivots hp[4];
     int piv_rc = 0;
     std::string piv_err;
     const float mpp = res->mpp;
-    std::thread piv_worker([&]() {
-        for (int c = 0; c < 4 && !piv_rc && ns > 0; c++) {
-            hp[c].off.resize((size_t)ns + 1);
-            int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
-            if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
-                piv_rc = MIMC3_ENODEV; piv_err = "mimc3_vmap: hipHostMalloc for the pivots failed"; break;
-            }
-            if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
-                                             static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
-            if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
-            if (rc) { piv_rc = rc; piv_err = mimc3_last_error(); }       // the message is thread-local: carry it over
-        }
-    });
+    const int device = mimc3_ctx_device(ctx);
+    std::thread piv_worker([&]() { piv_rc = mimc3::vmap_host_pivots(xs, ns, dt, mpp, p, H, W, device, hp, piv_err); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{piv_worker};
-
-    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
-    RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
-    res->cp_status = st;
-    if (st < 0) return 0;                                   // the CLI touches vmap.tar and gives up (:248-252)
-    res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1];
+    RC_TRY(mimc3::vmap_cp_offset(ctx, xyuvav, N, p, flag_cp, res));
+    if (res->cp_status < 0) return 0;                       // the CLI touches vmap.tar and gives up (:248-252)
     clk.mark("control-point offset", s);
-    if (ns == 0) { piv_worker.join(); return 0; }
-
-    // ---- the reference refuses nothing, it reads out of bounds; this library refuses (see mimc3_match_ncc_dlc)
-    int ocw_max = 0;
-    for (int k = 0; k < 4; k++) ocw_max = p->vec_ocw[k] > ocw_max ? p->vec_ocw[k] : ocw_max;
-    for (int32_t i = lo; i < hi; i++) {
-        const int32_t u0 = (int32_t)xyuvav[6 * (size_t)i + 2], v0 = (int32_t)xyuvav[6 * (size_t)i + 3];
-        if (u0 - ocw_max < 0 || u0 + ocw_max >= W || v0 - ocw_max < 0 || v0 + ocw_max >= H)
-            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: grid point " + std::to_string(i) + " chip leaves the image");
-    }
-
-    const size_t n = (size_t)ns;
-    Buf d_xy;
-    HIP_TRY(d_xy.alloc(48 * n));
-    HIP_TRY(hipMemcpyAsync(d_xy.p, xs, 48 * n, hipMemcpyHostToDevice, s));
-
-    // ---- pivots: forward and negated (:272-279) copies resident for all four image variants
-    struct Piv { Buf uv, uvn, off; int32_t mn = 0, mu = 0, mv = 0; int64_t total = 0; };
-    Piv piv[4];
     piv_worker.join();
     if (piv_rc) return mimc3::fail(piv_rc, piv_err);
-    for (int c = 0; c < 4; c++) {
-        const int64_t total = hp[c].total;
-        piv[c].mn = hp[c].mn; piv[c].mu = hp[c].mu; piv[c].mv = hp[c].mv; piv[c].total = total;
-        HIP_TRY(piv[c].uv.alloc(8 * (size_t)total));
-        HIP_TRY(piv[c].uvn.alloc(8 * (size_t)total));
-        HIP_TRY(piv[c].off.alloc(8 * (n + 1)));
-        HIP_TRY(hipMemcpyAsync(piv[c].uv.p, hp[c].uv, 8 * (size_t)total, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(piv[c].off.p, hp[c].off.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
-        RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv.as<int32_t>(), piv[c].uvn.as<int32_t>(), total, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-
-    clk.mark("pivots: join + upload", s);
-    // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
-    for (int kk = -1; kk <= 2; kk++) {
-        if (kk >= 0) {
-            RC_TRY(mimc3_ctx_filter_images(ctx, p->kernel[kk], p->kdim[kk][0], p->kdim[kk][1]));
-            clk.mark("filter + planes", s);
-        }
-        for (int c = 0; c < 4; c++) {
-            const int slot = (kk + 1) * 8 + c * 2;
-            float *fw = d_dp + (size_t)slot * n * 3, *sw = fw + n * 3;
-            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), ns, off[0], off[1], piv[c].uv.as<int32_t>(), piv[c].off.as<int64_t>(),
-                                           piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 0, fw, s));
-            RC_TRY(mimc3_match_ncc_dlc_dev(ctx, d_xy.as<double>(), ns, -off[0], -off[1], piv[c].uvn.as<int32_t>(), piv[c].off.as<int64_t>(),
-                                           piv[c].mn, piv[c].mu, piv[c].mv, p->vec_ocw[c], 1, sw, s));
-            RC_TRY(mimc3_negate_uv_dev(ctx, sw, ns, s));     // :289-293
-        }
-        clk.mark("8 matcher passes", s);
-    }
-    RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
-    HIP_TRY(hipStreamSynchronize(s));                       // d_dp is complete (and the pivot buffers are freed on return)
-    clk.mark("back to the raw pair", s);
-    return 0;
+    clk.mark("pivots: join", s);
+    if (ns == 0) return 0;
+    return mimc3::vmap_run_passes(ctx, xs, ns, res->offset_cp, hp, p, d_dp, 0);
 }
 
 // Post-processing of the complete candidate tensor d_dp [32][N][3] (device) and the unit conversion (:353-402).
@@ -261,9 +296,9 @@ extern "C" int mimc3_vmap_finish(mimc3_ctx *ctx, const double *xyuvav, int32_t N
     StageClock clk;
     hipStream_t s = static_cast<hipStream_t>(mimc3_ctx_stream(ctx));
     const size_t n = (size_t)N;
-    Buf d_xy, d_out5;
-    HIP_TRY(d_xy.alloc(48 * n));
-    HIP_TRY(d_out5.alloc(20 * n));
+    View d_xy, d_out5;
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotXyFull, 48 * n, &d_xy.p));
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotOut5, 20 * n, &d_out5.p));
     HIP_TRY(hipMemcpyAsync(d_xy.p, xyuvav, 48 * n, hipMemcpyHostToDevice, s));
     // ---- postprocess (:353)
     RC_TRY(mimc3_postprocess_dev(ctx, d_dp, 32, xyuvav, d_xy.as<double>(), res->dimx, res->dimy, dt, res->mpp, res->meter_per_spacing,
@@ -301,9 +336,9 @@ extern "C" int mimc3_vmap(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float
 {
     if (!ctx || !xyuvav || !p || !vx || !vy || !ex || !ey || !qual || !flag_cp || !res || N < 2)
         return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap: bad argument");
-    Buf d_dp;
-    HIP_TRY(d_dp.alloc(12 * (size_t)N * 32));
-    RC_TRY(mimc3_vmap_passes(ctx, xyuvav, N, dt, p, 0, N, d_dp.as<float>(), flag_cp, res));
+    void *d_dp = nullptr;
+    RC_TRY(mimc3_ctx_workspace(ctx, kSlotDp, 12 * (size_t)N * 32, &d_dp));
+    RC_TRY(mimc3_vmap_passes(ctx, xyuvav, N, dt, p, 0, N, static_cast<float *>(d_dp), flag_cp, res));
     if (res->cp_status < 0) return 0;
-    return mimc3_vmap_finish(ctx, xyuvav, N, dt, p, d_dp.as<float>(), vx, vy, ex, ey, qual, res);
+    return mimc3_vmap_finish(ctx, xyuvav, N, dt, p, static_cast<const float *>(d_dp), vx, vy, ex, ey, qual, res);
 }
