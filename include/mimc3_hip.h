@@ -249,6 +249,48 @@ int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt,
                       int32_t lo, int32_t hi, float *d_dp, uint8_t *flag_cp, mimc3_vmap_result *res);
 int mimc3_vmap_finish(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params,
                       const float *d_dp, float *vx, float *vy, float *ex, float *ey, float *qual, mimc3_vmap_result *res);
+/*      ... and in finer pieces, for a driver that measures the CP offset ONCE and shards by cost-balanced point sets:
+ *      mimc3_vmap_geometry = grid geometry only (:209-223); mimc3_vmap_cp = geometry + CP offset (:240-256) -> res, flag_cp;
+ *      mimc3_vmap_passes_points = host pivots + the 32 passes for ANY set of grid points xs [n][6] with the CP offset in
+ *      `res`, into d_dp [32][pass_stride][3] (pass_stride >= n points per pass slot; 0 = n). -------------------------------- */
+int mimc3_vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res);
+int mimc3_vmap_cp(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params, uint8_t *flag_cp,
+                  mimc3_vmap_result *res);
+int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_t n, float dt, const mimc3_vmap_params *params,
+                             const mimc3_vmap_result *res, float *d_dp, int64_t pass_stride);
+
+/* ---- e: multi-GPU.  The loop that shards is the reference's OpenMP loop over grid points (MIMC_module.c:816-838): grid
+ *      points are independent in the matcher, so each GPU matches its own share against the replicated pair and ONE
+ *      all-gather re-assembles the result.  Two forms:
+ *      (1) one process per GPU (torch.distributed / MPI launchers): mimc3_vmap_passes + the caller's own all-gather +
+ *          mimc3_vmap_finish, above;
+ *      (2) ONE process driving several GPUs, here: a host thread per device and an RCCL communicator over them
+ *          (ncclCommInitAll; RCCL is loaded with dlopen on first use -- env MIMC3_RCCL_LIB overrides librccl.so.1).
+ *          The MIMC3_hip command line takes this form with MIMC3_HIP_DEVICES=0,1,...
+ *      Shares are cost-balanced: mimc3_point_cost adds (4 + 6 npiv)(2 ocw + 1)^2 per point (NCC evaluations x chip area),
+ *      mimc3_partition_points cuts the grid into blocks of `block` consecutive points, deals them heaviest-first to the
+ *      least loaded rank and returns order[start[r] .. start[r+1]) = the points of rank r (each rank's blocks in grid
+ *      order); *imbalance = max load / mean load - 1.  Host code. ------------------------------------------------------ */
+int mimc3_point_cost(const int64_t *piv_off, int32_t N, int32_t ocw, double *cost /*[N], accumulated*/);
+int mimc3_partition_points(const double *cost, int32_t N, int32_t world, int32_t block, int32_t *order /*[N]*/,
+                           int32_t *start /*[world+1]*/, double *imbalance /*may be NULL*/);
+typedef struct mimc3_mgpu mimc3_mgpu;
+int  mimc3_mgpu_create(const int32_t *devices, int32_t ndev, mimc3_mgpu **out);   /* a context per device + the communicator */
+void mimc3_mgpu_destroy(mimc3_mgpu *mg);
+int32_t mimc3_mgpu_ndev(mimc3_mgpu *mg);
+mimc3_ctx *mimc3_mgpu_ctx(mimc3_mgpu *mg, int32_t rank);
+double mimc3_mgpu_last_imbalance(mimc3_mgpu *mg);                                 /* of the last call's partition */
+/*      the pair, replicated on every device (uploads run in parallel) */
+int mimc3_mgpu_set_images(mimc3_mgpu *mg, const float *i0, const float *i1, int32_t H, int32_t W);
+int mimc3_mgpu_set_images_u8(mimc3_mgpu *mg, const uint8_t *i0, const uint8_t *i1, int32_t H, int32_t W);
+int mimc3_mgpu_set_images_u16(mimc3_mgpu *mg, const uint16_t *i0, const uint16_t *i1, int32_t H, int32_t W);
+/*      mimc3_match_ncc_dlc / mimc3_vmap with the grid points sharded over the devices; same arguments, same results
+ *      (bit-identical: a point's result does not depend on which device computes it).  The CP offset of mimc3_mgpu_vmap
+ *      is measured once, on device 0; post-processing runs on device 0. */
+int mimc3_mgpu_match_ncc_dlc(mimc3_mgpu *mg, const double *xyuvav, int32_t N, const int32_t offset[2], const int32_t *piv_uv,
+                             const int64_t *piv_off, int32_t ocw, int32_t swap, float *out /*[N][3] host*/);
+int mimc3_mgpu_vmap(mimc3_mgpu *mg, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *params, float *vx, float *vy,
+                    float *ex, float *ey, float *qual, uint8_t *flag_cp, mimc3_vmap_result *res);
 
 /*      small device helpers the driver is built from: the context's own stream; (du,dv) -> (-du,-dv) of a swapped
  *      pass (MIMC_main.c:289-293); cluster map -> five planes (mimc2_postprocess :937-970 /

@@ -109,10 +109,34 @@ _lib.mimc3_vmap_passes.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(V
                                    np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(VmapResult)]
 _lib.mimc3_vmap_finish.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), _vp, _f32p, _f32p, _f32p, _f32p, _f32p,
                                    C.POINTER(VmapResult)]
+_lib.mimc3_vmap_geometry.argtypes = [_f64p, C.c_int32, C.POINTER(VmapResult)]
+_lib.mimc3_vmap_cp.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"),
+                               C.POINTER(VmapResult)]
+_lib.mimc3_vmap_passes_points.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), C.POINTER(VmapResult), _vp, C.c_int64]
 _lib.mimc3_ctx_set_path.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_path.argtypes = [_vp]
 _lib.mimc3_ctx_enable_timing.argtypes = [_vp, C.c_int32]
 _lib.mimc3_ctx_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
+
+
+_lib.mimc3_point_cost.argtypes = [_i64p, C.c_int32, C.c_int32, _f64p]
+_lib.mimc3_partition_points.argtypes = [_f64p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, C.POINTER(C.c_double)]
+_lib.mimc3_mgpu_create.argtypes = [_i32p, C.c_int32, C.POINTER(_vp)]
+_lib.mimc3_mgpu_destroy.argtypes = [_vp]
+_lib.mimc3_mgpu_destroy.restype = None
+_lib.mimc3_mgpu_ndev.argtypes = [_vp]
+_lib.mimc3_mgpu_ctx.argtypes = [_vp, C.c_int32]
+_lib.mimc3_mgpu_ctx.restype = _vp
+_lib.mimc3_mgpu_last_imbalance.argtypes = [_vp]
+_lib.mimc3_mgpu_last_imbalance.restype = C.c_double
+_lib.mimc3_mgpu_set_images.argtypes = [_vp, _f32p, _f32p, C.c_int32, C.c_int32]
+_lib.mimc3_mgpu_set_images_u8.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_mgpu_set_images_u16.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32]
+_lib.mimc3_mgpu_match_ncc_dlc.argtypes = [_vp, _f64p, C.c_int32, _i32p, _i32p, _i64p, C.c_int32, C.c_int32, _f32p]
+_lib.mimc3_mgpu_vmap.argtypes = [_vp, _f64p, C.c_int32, C.c_float, C.POINTER(VmapParams), _f32p, _f32p, _f32p, _f32p, _f32p,
+                                 np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(VmapResult)]
+_lib.mimc3_ctx_device.argtypes = [_vp]
+_lib.mimc3_ctx_workspace.argtypes = [_vp, C.c_int32, C.c_size_t, C.POINTER(_vp)]
 
 
 class Mimc3Error(RuntimeError):
@@ -145,6 +169,15 @@ def get_uv_pivot(xyuvav, dt, mpp, ocw, H, W, aw_sf=1.8, aw_cre=10.0):
     _check(_lib.mimc3_get_uv_pivot(xy, n, dt, mpp, aw_sf, aw_cre, ocw, H, W, off, uv.ctypes.data_as(_vp), tot.value,
                                    C.byref(tot)), "get_uv_pivot")
     return off, uv
+
+
+def get_uv_pivot_counts(xyuvav, dt, mpp, ocw, H, W, aw_sf=1.8, aw_cre=10.0):
+    """The counting half of get_uv_pivot (MIMC_module.c:576-585): CSR offsets only (piv_off int64[N+1])."""
+    xy = np.ascontiguousarray(xyuvav, np.float64)
+    off = np.zeros(xy.shape[0] + 1, np.int64)
+    tot = C.c_int64(0)
+    _check(_lib.mimc3_get_uv_pivot(xy, xy.shape[0], dt, mpp, aw_sf, aw_cre, ocw, H, W, off, None, 0, C.byref(tot)), "get_uv_pivot")
+    return off
 
 
 def pivot_extent(piv_off, piv_uv):
@@ -192,6 +225,85 @@ def pinned_empty(shape, dtype):
 
 
 _PIN_KEEP = {}
+
+
+def point_cost(piv_off, ocw, cost=None):
+    """mimc3_point_cost: adds (4 + 6 npiv)(2 ocw + 1)^2 per point to `cost` (float64[N], created when None)."""
+    off = np.ascontiguousarray(piv_off, np.int64)
+    n = off.shape[0] - 1
+    if cost is None:
+        cost = np.zeros(n, np.float64)
+    _check(_lib.mimc3_point_cost(off, n, ocw, cost), "point_cost")
+    return cost
+
+
+def partition_points(cost, world, block=1024):
+    """mimc3_partition_points: cost-balanced block-cyclic shares.  Returns (order int32[N], start int32[world+1],
+    imbalance = max load / mean load - 1); rank r owns grid points order[start[r]:start[r+1]]."""
+    cost = np.ascontiguousarray(cost, np.float64)
+    n = cost.shape[0]
+    order = np.empty(n, np.int32)
+    start = np.empty(world + 1, np.int32)
+    imb = C.c_double(0)
+    _check(_lib.mimc3_partition_points(cost, n, world, block, order, start, C.byref(imb)), "partition_points")
+    return order, start, imb.value
+
+
+class MultiGpu:
+    """mimc3_mgpu: ONE process driving several GPUs (a host thread per device, RCCL communicator over them)."""
+
+    def __init__(self, devices):
+        self._h = _vp()
+        dv = np.ascontiguousarray(devices, np.int32)
+        _check(_lib.mimc3_mgpu_create(dv, dv.shape[0], C.byref(self._h)), "mgpu_create")
+        self.ndev = dv.shape[0]
+
+    def close(self):
+        if self._h:
+            _lib.mimc3_mgpu_destroy(self._h)
+            self._h = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_images(self, i0, i1):
+        if i0.dtype in (np.uint8, np.uint16):
+            i0 = np.ascontiguousarray(i0); i1 = np.ascontiguousarray(i1)
+            fn = _lib.mimc3_mgpu_set_images_u8 if i0.dtype == np.uint8 else _lib.mimc3_mgpu_set_images_u16
+            _check(fn(self._h, i0.ctypes.data, i1.ctypes.data, i0.shape[0], i0.shape[1]), "mgpu_set_images_raw")
+        else:
+            i0 = np.ascontiguousarray(i0, np.float32); i1 = np.ascontiguousarray(i1, np.float32)
+            _check(_lib.mimc3_mgpu_set_images(self._h, i0, i1, i0.shape[0], i0.shape[1]), "mgpu_set_images")
+
+    def matching_ncc_dlc_2(self, xyuvav, offset, piv_off, piv_uv, ocw, swap=False):
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        out = np.empty((xy.shape[0], 3), np.float32)
+        _check(_lib.mimc3_mgpu_match_ncc_dlc(self._h, xy, xy.shape[0], np.ascontiguousarray(offset, np.int32),
+                                             np.ascontiguousarray(piv_uv, np.int32), np.ascontiguousarray(piv_off, np.int64), ocw,
+                                             1 if swap else 0, out), "mgpu_matching_ncc_dlc_2")
+        return out
+
+    def vmap(self, xyuvav, dt, **kw):
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        n = xy.shape[0]
+        p, _keep = Context._vmap_params(**kw)
+        planes = [np.empty(n, np.float32) for _ in range(5)]
+        flag = np.zeros(n, np.uint8)
+        r = VmapResult()
+        _check(_lib.mimc3_mgpu_vmap(self._h, xy, n, dt, C.byref(p), *planes, flag, C.byref(r)), "mgpu_vmap")
+        return Context._vmap_out(r, flag, planes)
+
+    def last_imbalance(self):
+        return float(_lib.mimc3_mgpu_last_imbalance(self._h))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,6 +456,27 @@ class Context:
         r = VmapResult()
         _check(_lib.mimc3_vmap_passes(self._h, xy, xy.shape[0], dt, C.byref(p), lo, hi, d_dp, flag, C.byref(r)), "vmap_passes")
         return r, flag
+
+    def vmap_geometry(self, xyuvav):
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        r = VmapResult()
+        _check(_lib.mimc3_vmap_geometry(xy, xy.shape[0], C.byref(r)), "vmap_geometry")
+        return r
+
+    def vmap_cp(self, xyuvav, dt, **kw):
+        """geometry + CP offset on the whole grid -> (VmapResult, flag_cp)"""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        p, _keep = self._vmap_params(**kw)
+        flag = np.zeros(xy.shape[0], np.uint8)
+        r = VmapResult()
+        _check(_lib.mimc3_vmap_cp(self._h, xy, xy.shape[0], dt, C.byref(p), flag, C.byref(r)), "vmap_cp")
+        return r, flag
+
+    def vmap_passes_points(self, xs, dt, r, d_dp, pass_stride=0, **kw):
+        """the 32 passes for the grid points xs [n][6] (any subset) into the device tensor d_dp [32][pass_stride][3]"""
+        xs = np.ascontiguousarray(xs, np.float64)
+        p, _keep = self._vmap_params(**kw)
+        _check(_lib.mimc3_vmap_passes_points(self._h, xs, xs.shape[0], dt, C.byref(p), C.byref(r), d_dp, pass_stride), "vmap_passes_points")
 
     def vmap_finish(self, xyuvav, dt, d_dp_full, r, flag, **kw):
         """mimc3_vmap_finish on the complete candidate tensor [32][N][3] (device pointer); same dict as vmap()."""

@@ -10,8 +10,9 @@
 //   * outputs: vmap_<t0>_<t1>_{x,y}.GMA (f64 1 x dim), _{vx,vy,ex,ey,qual}.GMA (f32 dimy x dimx), _flagcp.GMA (u8),
 //     _meta.txt (7 key=value lines) (:404-447)
 // Everything between "inputs loaded" and "save the output" is mimc3_vmap() on the GPU; there is no CPU path.
-// Environment: MIMC3_HIP_DEVICE (default 0), MIMC3_CP_SEED (pin the control-point shuffle; default time(NULL) like
-// the reference).
+// Environment: MIMC3_HIP_DEVICE (default 0); MIMC3_HIP_DEVICES=0,1,... shards the grid points over several GPUs of the node
+// (one host thread per device, RCCL all-gather of the candidate blocks: mimc3_mgpu_vmap); MIMC3_CP_SEED (pin the
+// control-point shuffle; default time(NULL) like the reference).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -152,46 +153,64 @@ int main(int argc, char *argv[])
     std::vector<double> xy;
     int32_t N = 0, ncol = 0;
     if (!load_gma_double(argv[3], xy, N, ncol) || ncol != 6) { fprintf(stderr, "cannot read %s as an [N][6] float64 .GMA\n", argv[3]); return 2; }
-    // the HIP runtime and the device context come up on a second thread while this one decodes the TIFFs
+    // the HIP runtime and the device context(s) come up on a second thread while this one decodes the TIFFs
     const char *dev = getenv("MIMC3_HIP_DEVICE");
+    std::vector<int32_t> devs;
+    if (const char *dl = getenv("MIMC3_HIP_DEVICES")) {
+        for (const char *q = dl; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devs.push_back((int32_t)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+        if (devs.empty()) { fprintf(stderr, "MIMC3_HIP_DEVICES: expected a comma-separated list of device ordinals\n"); return 2; }
+    }
     mimc3_ctx *ctx = nullptr;
+    mimc3_mgpu *mg = nullptr;
     int ctx_rc = 0;
     std::string ctx_err;
     std::thread ctx_thread([&]() {
-        ctx_rc = mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx);
+        ctx_rc = devs.empty() ? mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx) : mimc3_mgpu_create(devs.data(), (int32_t)devs.size(), &mg);
         if (ctx_rc) ctx_err = mimc3_last_error();
     });
+    auto cleanup = [&]() { if (ctx) mimc3_ctx_destroy(ctx); if (mg) mimc3_mgpu_destroy(mg); ctx = nullptr; mg = nullptr; };
     RawImage i0, i1;
     const bool tiff_ok = load_tiff(argv[1], i0) && load_tiff(argv[2], i1);
     ctx_thread.join();
-    if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); if (ctx) mimc3_ctx_destroy(ctx); return 2; }
-    if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); if (ctx) mimc3_ctx_destroy(ctx); return 2; }
+    if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); cleanup(); return 2; }
+    if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); cleanup(); return 2; }
     if (ctx_rc) { fprintf(stderr, "%s\n", ctx_err.c_str()); return 3; }
     const int32_t H = i0.H, W = i0.W;
     int rc;
-    if (i0.bpp == 1 && i1.bpp == 1) rc = mimc3_ctx_set_images_u8(ctx, i0.px.data(), i1.px.data(), H, W);
-    else if (i0.bpp == 2 && i1.bpp == 2)
-        rc = mimc3_ctx_set_images_u16(ctx, reinterpret_cast<const uint16_t *>(i0.px.data()), reinterpret_cast<const uint16_t *>(i1.px.data()), H, W);
-    else {                                    // one 8-bit and one 16-bit file: widen on the host like the reference
+    if (i0.bpp == 1 && i1.bpp == 1)
+        rc = mg ? mimc3_mgpu_set_images_u8(mg, i0.px.data(), i1.px.data(), H, W) : mimc3_ctx_set_images_u8(ctx, i0.px.data(), i1.px.data(), H, W);
+    else if (i0.bpp == 2 && i1.bpp == 2) {
+        const uint16_t *q0 = reinterpret_cast<const uint16_t *>(i0.px.data()), *q1 = reinterpret_cast<const uint16_t *>(i1.px.data());
+        rc = mg ? mimc3_mgpu_set_images_u16(mg, q0, q1, H, W) : mimc3_ctx_set_images_u16(ctx, q0, q1, H, W);
+    } else {                                  // one 8-bit and one 16-bit file: widen on the host like the reference
         std::vector<float> f0((size_t)H * W), f1((size_t)H * W);
         auto widen = [&](const RawImage &im, std::vector<float> &f) {
             if (im.bpp == 1) for (size_t k = 0; k < f.size(); k++) f[k] = (float)im.px[k];
             else { const uint16_t *q = reinterpret_cast<const uint16_t *>(im.px.data()); for (size_t k = 0; k < f.size(); k++) f[k] = (float)q[k]; }
         };
         widen(i0, f0); widen(i1, f1);
-        rc = mimc3_ctx_set_images(ctx, f0.data(), f1.data(), H, W);
+        rc = mg ? mimc3_mgpu_set_images(mg, f0.data(), f1.data(), H, W) : mimc3_ctx_set_images(ctx, f0.data(), f1.data(), H, W);
     }
-    if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); return 3; }
+    if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); cleanup(); return 3; }
 
     std::vector<float> vx(N), vy(N), ex(N), ey(N), qual(N);
     std::vector<uint8_t> flag(N);
     mimc3_vmap_result r{};
-    if (mimc3_vmap(ctx, xy.data(), N, dt, &p, vx.data(), vy.data(), ex.data(), ey.data(), qual.data(), flag.data(), &r)) {
+    rc = mg ? mimc3_mgpu_vmap(mg, xy.data(), N, dt, &p, vx.data(), vy.data(), ex.data(), ey.data(), qual.data(), flag.data(), &r)
+            : mimc3_vmap(ctx, xy.data(), N, dt, &p, vx.data(), vy.data(), ex.data(), ey.data(), qual.data(), flag.data(), &r);
+    if (rc) {
         fprintf(stderr, "%s\n", mimc3_last_error());
-        mimc3_ctx_destroy(ctx);
+        cleanup();
         return 3;
     }
-    mimc3_ctx_destroy(ctx);
+    if (mg) printf("grid points sharded over %d GPU(s), work imbalance %.1f %%\n", (int)mimc3_mgpu_ndev(mg), 100.0 * mimc3_mgpu_last_imbalance(mg));
+    cleanup();
     printf("MPP=%f, grid spacing=%f, meter per spacing=%fm\nDimension of the vmap: %d by %d (mapy / mapx)\n", r.mpp, r.spacing_grid,
            r.meter_per_spacing, r.dimy, r.dimx);
     if (r.cp_status < 0) {                                                              // :246-252

@@ -286,6 +286,37 @@ extern "C" int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N
     return mimc3::vmap_run_passes(ctx, xs, ns, res->offset_cp, hp, p, d_dp, 0);
 }
 
+// The same in pieces, for a multi-process driver that measures the CP offset once and shards by cost-balanced point sets:
+extern "C" int mimc3_vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
+{
+    if (!xyuvav || !res || N < 2) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_geometry: bad argument");
+    std::memset(res, 0, sizeof(*res));
+    return mimc3::vmap_geometry(xyuvav, N, res);
+}
+
+extern "C" int mimc3_vmap_cp(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, uint8_t *flag_cp,
+                             mimc3_vmap_result *res)
+{
+    (void)dt;
+    if (!ctx || !xyuvav || !p || !flag_cp || !res || N < 2) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_cp: bad argument");
+    std::memset(res, 0, sizeof(*res));
+    RC_TRY(mimc3::vmap_geometry(xyuvav, N, res));
+    return mimc3::vmap_cp_offset(ctx, xyuvav, N, p, flag_cp, res);
+}
+
+extern "C" int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_t n, float dt, const mimc3_vmap_params *p,
+                                        const mimc3_vmap_result *res, float *d_dp, int64_t pass_stride)
+{
+    if (!ctx || !xs || !p || !res || !d_dp || n < 1 || res->cp_status < 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_passes_points: bad argument");
+    int32_t H = 0, W = 0;
+    RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
+    mimc3::HostPivots hp[4];
+    std::string err;
+    int rc = mimc3::vmap_host_pivots(xs, n, dt, res->mpp, p, H, W, mimc3_ctx_device(ctx), hp, err);
+    if (rc) return mimc3::fail(rc, err);
+    return mimc3::vmap_run_passes(ctx, xs, n, res->offset_cp, hp, p, d_dp, pass_stride > 0 ? (size_t)pass_stride : 0);
+}
+
 // Post-processing of the complete candidate tensor d_dp [32][N][3] (device) and the unit conversion (:353-402).
 // `res` is the one mimc3_vmap_passes filled (its geometry is used, cp_subint is added).
 extern "C" int mimc3_vmap_finish(mimc3_ctx *ctx, const double *xyuvav, int32_t N, float dt, const mimc3_vmap_params *p, const float *d_dp,
