@@ -4,16 +4,20 @@
     python bench.py --gpus N --steps K --warmup W           (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one matcher pass (matching_ncc_dlc_2) over one batch of synthetic grid points.
-Workload at N=1 = BASELINE configs[1]: 4096x4096 synthetic pair, 200,000 grid points (500x400),
-ocw 16 (33x33 chip), ~15 DLC pivots (65x65 window).  Inputs (both images, xyuvav, pivot CSR) are
-resident in HBM before the timed region.  At N>1 every rank matches its own 200,000-point lattice
-on the replicated pair (lattice r is shifted r px in x: together an N-times denser grid; weak
-scaling), then the (u,v,ncc) field is re-assembled on every GPU with one RCCL all-gather.
+One "step" = one matcher pass (matching_ncc_dlc_2, MIMC_module.c:805-842) over one batch of synthetic grid points.
+Workload at N=1 = BASELINE configs[1] (C2): 4096x4096 synthetic pair, 200,000 grid points (500x400), ocw 16 (33x33 chip),
+~15 DLC pivots (65x65 window).  Inputs (both images, xyuvav, pivot CSR) are resident in HBM before the timed region:
+`value` is the kernel-only rate; `value_incl_io` is SURVEY 8(d)(i)'s figure with the pivot/xyuvav upload and the result
+download inside every step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1,
-`cpu_baseline` (the compiled reference OpenMP path when oracle/_ref travelled here, else the
-parity-verified C restatement) and a parity figure against it.
+At N>1 (one rank per GPU, torch.distributed, backend nccl = RCCL) the headline is BASELINE configs[2] (C3): the SAME
+200,000 points sharded over the ranks in cost-balanced blocks (strong scaling), every step = the rank's share + ONE
+all-gather of the padded (du,dv,ncc) blocks + the re-ordering to grid order.  The weak-scaling figure (every rank matches
+its own 200,000-point lattice) is reported next to it in `weak`.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1, `cpu_baseline` (the compiled
+reference OpenMP path when oracle/_ref travelled here, else the parity-verified C restatement), a parity figure against
+it, and `f32_path` (the same workload forced onto the tiled f32 kernel, what 16-bit imagery gets).
 """
 import argparse
 import json
@@ -27,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+KERNEL_NAMES = {"u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dlc_px<PxF32>", "u16_scaled": "match_ncc_dlc_px<PxU16>",
+                "u8_offset": "match_ncc_dlc_px<PxU8o>", "general_f32": "match_ncc_dlc_f32"}
+DTYPES = {"u8_exact": "u8", "u16_scaled": "u16", "u8_offset": "u8"}
 
 
 def algorithmic_bytes(piv_off, piv_uv, ocw):
@@ -39,6 +46,42 @@ def algorithmic_bytes(piv_off, piv_uv, ocw):
     return int((chip + 4 * (2 * dx2 + 1) * (2 * dy2 + 1) + 48 + 8 * npiv + 12).sum())
 
 
+class Leg:
+    """one resident matcher workload on this rank: device copies of xyuvav + pivot CSR, an output block of `per` rows"""
+
+    def __init__(self, torch, api, dev, xy, piv_off, piv_uv, per):
+        self.n = xy.shape[0]
+        self.per = per
+        self.extent = api.pivot_extent(piv_off, piv_uv) if self.n else (1, 0, 0)
+        self.d_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(dev)
+        self.d_uv = torch.from_numpy(np.ascontiguousarray(piv_uv)).to(dev)
+        self.d_off = torch.from_numpy(np.ascontiguousarray(piv_off)).to(dev)
+        self.d_out = torch.full((per, 3), float("nan"), dtype=torch.float32, device=dev)
+
+
+def timed(torch, dist, world, dev, step, steps, warmup):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+    Returns (seconds, mean ms between the HIP events recorded around the kernel launch of each step)."""
+    for _ in range(warmup):
+        step(None)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,9 +91,10 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "general", "f32", "u16"],
                     help="auto: exact u8 kernel when the pair is 8-bit integral; f32: the register-tiled f32 kernel "
                          "(what 16-bit / filtered imagery gets); general: force the fallback f32 kernel")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank matches its own lattice of the config's size (default); "
-                         "strong: the config's points are sharded across ranks (BASELINE configs[2])")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="which figure is the headline `value` at N>1 (the other one is reported too): strong = the config's "
+                         "points sharded across the ranks (BASELINE configs[2], default); weak = every rank matches its own "
+                         "lattice of the config's size")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default). gloo + MIMC3_BENCH_ONE_DEVICE=1 rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--qm-sweeps", type=int, default=10,
@@ -58,18 +102,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-program", action="store_true",
                     help="skip the extra `program` object (the reference program's whole data path, mimc3_vmap, once)")
+    ap.add_argument("--no-f32-path", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
     import torch
-    from mimc3_amd import api, synth   # raises if libmimc3_hip.so is missing: no CPU fallback
+    from mimc3_amd import api, shard, synth   # raises if libmimc3_hip.so is missing: no CPU fallback
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if os.environ.get("MIMC3_BENCH_ONE_DEVICE") == "1":
@@ -84,121 +128,185 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    collective = "none" if world == 1 else ("RCCL all-gather (torch.distributed nccl backend)" if args.backend == "nccl"
+                                            else "gloo all-gather through host memory (rehearsal backend)")
 
     # ---- inputs (seeded; identical images on every rank) -------------------------------------
     case = synth.make_case(args.config)
     H, W = case.i0.shape
-    from mimc3_amd import shard
-    xy = case.xyuvav.copy()
-    n_job = xy.shape[0] * (world if args.scaling == "weak" else 1)   # grid points of the whole job per step
-    if args.scaling == "weak":
-        if rank:                               # rank r's lattice: shifted r px in x
-            xy[:, 2] += rank
-            xy[:, 0] += rank * case.mpp
-        per = xy.shape[0]
-    else:
-        lo, hi, per = shard.block_range(xy.shape[0], world, rank)
-        xy = np.ascontiguousarray(xy[lo:hi])
-    n = xy.shape[0]
-    piv_off, piv_uv = api.get_uv_pivot(xy, case.dt, case.mpp, case.ocw, H, W)
-    extent = api.pivot_extent(piv_off, piv_uv)
-    alg_bytes = algorithmic_bytes(piv_off, piv_uv, case.ocw)
-
-    t_h2d0 = time.perf_counter()
-    d_i0 = torch.from_numpy(case.i0).to(dev)
-    d_i1 = torch.from_numpy(case.i1).to(dev)
-    torch.cuda.synchronize()
-    t_h2d = time.perf_counter() - t_h2d0
-    d_xy = torch.from_numpy(xy).to(dev)
-    d_uv = torch.from_numpy(piv_uv).to(dev)
-    d_off = torch.from_numpy(piv_off).to(dev)
-    d_out = torch.full((per, 3), float("nan"), dtype=torch.float32, device=dev)   # padded to the block size
-    d_all = torch.empty((world * per, 3), dtype=torch.float32, device=dev) if world > 1 else None
-
+    xy_all = case.xyuvav
+    n_all = xy_all.shape[0]
     ctx = api.Context(local_rank)
-    t_prep0 = time.perf_counter()
-    ctx.set_images_dev(d_i0.data_ptr(), d_i1.data_ptr(), H, W, keep=(d_i0, d_i1))   # builds + proves the u8 planes
-    t_prep = time.perf_counter() - t_prep0
+    raw_ok = bool(case.i0.max() <= 255 and case.i1.max() <= 255)
+    t0 = time.perf_counter()
+    ctx.set_images(case.i0, case.i1)                       # f32 pair from pageable memory (through the pinned staging chunks)
+    t_h2d_f32 = time.perf_counter() - t0
+    t_h2d_raw = None
+    if raw_ok:                                             # the pair as the 8-bit TIFF holds it, from pinned memory
+        p0, p1 = api.pinned_empty((H, W), np.uint8), api.pinned_empty((H, W), np.uint8)
+        p0[:] = case.i0; p1[:] = case.i1
+        t0 = time.perf_counter()
+        ctx.set_images_raw(p0, p1)
+        t_h2d_raw = time.perf_counter() - t0
     ctx.set_path(args.path)
     stream = torch.cuda.current_stream()
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record(stream)
-        ctx.matching_ncc_dlc_2_dev(d_xy.data_ptr(), n, case.offset, d_uv.data_ptr(), d_off.data_ptr(), extent,
-                                   case.ocw, d_out.data_ptr(), stream=stream.cuda_stream)
-        if ev is not None:
-            ev[1].record(stream)
-        if world > 1:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI: the one exchange step
-            else:
-                dist.all_gather(list(d_all.view(world, per, 3).unbind(0)), d_out)
+    piv_off, piv_uv = api.get_uv_pivot(xy_all, case.dt, case.mpp, case.ocw, H, W)
 
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    def make_step(leg, gather=None):
+        def step(ev):
+            if ev is not None:
+                ev[0].record(stream)
+            if leg.n:
+                ctx.matching_ncc_dlc_2_dev(leg.d_xy.data_ptr(), leg.n, case.offset, leg.d_uv.data_ptr(), leg.d_off.data_ptr(),
+                                           leg.extent, case.ocw, leg.d_out.data_ptr(), stream=stream.cuda_stream)
+            if ev is not None:
+                ev[1].record(stream)
+            if gather is not None:
+                gather(leg)
+        return step
+
+    result = {}
+    if world == 1:
+        leg = Leg(torch, api, dev, xy_all, piv_off, piv_uv, n_all)
+        elapsed, kern_ms = timed(torch, dist, world, dev, make_step(leg), args.steps, args.warmup)
+        alg_bytes = algorithmic_bytes(piv_off, piv_uv, case.ocw)
+        n_job, n_rank0, scaling = n_all, n_all, "weak"
+        got = leg.d_out.cpu().numpy()
+        path = ctx.last_path()
+    else:
+        # ---- strong: BASELINE configs[2], the config's points in cost-balanced shares
+        cost = api.point_cost(piv_off, case.ocw)
+        order, start, per, imb = shard.balanced_shares(cost, world)
+        mine = order[start[rank]:start[rank + 1]]
+        sxy, soff, suv = shard.gather_problem(xy_all, piv_off, piv_uv, mine)
+        leg_s = Leg(torch, api, dev, sxy, soff, suv, per)
+        field = {}
+        to_grid = shard.Unpermute(order, start, per, dev)
+
+        def gather_strong(leg):
+            g = shard.all_gather_blocks(leg.d_out, per, world)                 # the ONE exchange: [world][per][3]
+            field["full"] = to_grid(g)                                         # grid order, on every rank
+
+        el_s, km_s = timed(torch, dist, world, dev, make_step(leg_s, gather_strong), args.steps, args.warmup)
+        # ---- weak: every rank its own lattice of the config's size (lattice r shifted r px in x: an N-times denser grid)
+        xy_w = xy_all.copy()
+        xy_w[:, 2] += rank; xy_w[:, 0] += rank * case.mpp
+        woff, wuv = api.get_uv_pivot(xy_w, case.dt, case.mpp, case.ocw, H, W)
+        leg_w = Leg(torch, api, dev, xy_w, woff, wuv, n_all)
+
+        def gather_weak(leg):
+            field["weak"] = shard.all_gather_blocks(leg.d_out, n_all, world)
+
+        el_w, km_w = timed(torch, dist, world, dev, make_step(leg_w, gather_weak), args.steps, args.warmup)
+        strong = {"value": n_all * args.steps / el_s, "ms_per_step": el_s / args.steps * 1e3, "kernel_ms_rank0": km_s,
+                  "grid_points_rank0": int(leg_s.n), "points_per_step": n_all, "work_imbalance": imb,
+                  "what": f"{args.config}'s {n_all} points in cost-balanced shares of {shard.default_block(n_all, world)}-point blocks"}
+        weak = {"value": n_all * world * args.steps / el_w, "ms_per_step": el_w / args.steps * 1e3, "kernel_ms_rank0": km_w,
+                "grid_points_rank0": n_all, "points_per_step": n_all * world,
+                "what": f"every rank its own {n_all}-point lattice (shifted r px), all-gather of [{world}][{n_all}][3]"}
+        result["strong"], result["weak"] = strong, weak
+        if args.scaling == "strong":
+            elapsed, kern_ms, n_job, n_rank0, scaling = el_s, km_s, n_all, leg_s.n, "strong"
+            alg_bytes = algorithmic_bytes(soff, suv, case.ocw) if leg_s.n else 0
+        else:
+            elapsed, kern_ms, n_job, n_rank0, scaling = el_w, km_w, n_all * world, n_all, "weak"
+            alg_bytes = algorithmic_bytes(woff, wuv, case.ocw)
+        got = field["full"].cpu().numpy()
+        path = ctx.last_path()
 
     if rank == 0:
-        total_pts = n_job * args.steps
-        value = total_pts / elapsed
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        value = n_job * args.steps / elapsed
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        kname = KERNEL_NAMES.get(path, path)
         res = {
             "metric": "grid-points/s (DLC NCC match)", "value": value, "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
-            "dtype": ("u8 pixels, exact u32 dot4 sums, f64 NCC" if ctx.last_path() == "u8_exact"
-                      else "f32 pixels, f32 products, f64 sums and NCC"),
-            "kernel_path": ctx.last_path(),
+            "dtype": DTYPES.get(path, "f32 products, f64 sums"),
+            "kernel_path": path,
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {W}x{H} synthetic shifted pair, {n} grid points on rank 0 of {n_job} per step "
-                                   f"({case.dimx}x{case.dimy}), ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), "
-                                   f"{extent[0]} pivots max, window up to {2 * (extent[1] + case.ocw + 2) + 1}^2",
-                       "grid_points_per_gpu": n, "image": [H, W], "ocw": case.ocw,
-                       "parallelism": f"grid-point shard x{world}" + (", RCCL all-gather of [N,3]" if world > 1 else "")},
+            "config": {"workload": f"{'C3' if (world > 1 and scaling == 'strong' and args.config == 'C2') else args.config}: {W}x{H} synthetic "
+                                   f"shifted pair, {n_job} grid points per step ({n_rank0} on rank 0; grid {case.dimx}x{case.dimy}), "
+                                   f"ocw {case.ocw} ({2 * case.ocw + 1}^2 chip), up to {int((piv_off[1:] - piv_off[:-1]).max())} pivots, "
+                                   f"window up to {2 * (int(np.abs(piv_uv).max()) + case.ocw + 2) + 1}^2",
+                       "grid_points_rank0": int(n_rank0), "image": [H, W], "ocw": case.ocw,
+                       "parallelism": f"grid-point shard x{world}", "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {"u8_exact": "match_ncc_dlc_u8", "f32_tiled": "match_ncc_dlc_px<PxF32>", "u16_scaled": "match_ncc_dlc_px<PxU16>"}.get(ctx.last_path(), "match_ncc_dlc_f32"),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "h2d_images_s": t_h2d, "u8_plane_prep_s": t_prep,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "timer": "HIP events recorded on the launch stream around each of the K timed launches (rank 0)"},
+            "h2d_images_s": t_h2d_raw if t_h2d_raw is not None else t_h2d_f32,
+            "h2d_images": {"raw_dn_pinned_s": t_h2d_raw, "f32_pageable_s": t_h2d_f32,
+                           "note": "pair upload incl. device-side widening + plane build; raw = 1 B/px as the 8-bit TIFF holds it"},
         }
+        res.update(result)
         try:   # HBM bytes per launch measured by rocprofv3 PMC passes of this same command (profiles/)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[args.config][res["roofline"]["kernel"]]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[args.config][kname]
             res["roofline"]["traffic"] = tr["bytes"]
-            res["roofline"]["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+            res["roofline"]["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; measured in separate --pmc passes, not in this run)"
         except Exception:
             pass
-        got = d_out[:n].cpu().numpy()
         valid = got[:, 2] > -2.5
         res["check"] = {"valid_frac": float(valid.mean()),
                         "median_du_dv": [float(np.nanmedian(got[:, 0])), float(np.nanmedian(got[:, 1]))],
                         "true_shift": list(case.shift)}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], res["parity"] = cpu_baseline(case, xy, piv_off, piv_uv, got, args.cpu_sample)
+        if world == 1:
+            res["incl_io"] = io_leg(api, ctx, case, xy_all, piv_off, piv_uv, min(args.steps, 10))
+            res["value_incl_io"] = res["incl_io"]["value"]
+            cpu = None
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"], res["parity"], cpu = cpu_baseline(case, xy_all, piv_off, piv_uv, got, args.cpu_sample)
+            if not args.no_f32_path and args.path == "auto" and path != "f32_tiled":
+                res["f32_path"] = f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, cpu)
+                ctx.set_path(args.path)
         if args.qm_sweeps > 0:
             res["qm"] = qm_leg(torch, api, synth, ctx, dev, case, args.qm_sweeps, check=(world == 1 and not args.no_cpu_baseline))
         if world == 1 and not args.no_program:
-            res["program"] = program_leg(api, ctx, xy)
+            res["program"] = program_leg(api, ctx, xy_all)
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps):
+    """one pass INCLUDING the xyuvav / pivot upload and the result download (host entry point
+    mimc3_match_ncc_dlc from pinned host arrays; the images stay resident as in the CLI's 32-pass schedule)."""
+    H, W = case.i0.shape
+    pxy = api.pinned_empty(xy.shape, np.float64); pxy[:] = xy
+    puv = api.pinned_empty(piv_uv.shape, np.int32); puv[:] = piv_uv
+    poff = api.pinned_empty(piv_off.shape, np.int64); poff[:] = piv_off
+    ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw)
+    dt = (time.perf_counter() - t0) / steps
+    nbytes = pxy.nbytes + puv.nbytes + poff.nbytes + 12 * xy.shape[0]
+    return {"value": xy.shape[0] / dt, "ms_per_step": dt * 1e3, "steps": steps, "bytes_over_pcie_per_step": int(nbytes),
+            "what": "upload xyuvav + pivot CSR, bounds check, kernel, download [N][3]; pair resident"}
+
+
+def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, cpu):
+    """The same C2 workload forced onto the register-tiled f32 kernel (f32 products, f64 sums): what a 16-bit pair gets."""
+    ctx.set_path("f32")
+    leg.d_out.fill_(float("nan"))
+    elapsed, kern_ms = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+    alg = algorithmic_bytes(piv_off, piv_uv, case.ocw)
+    ach = alg / (kern_ms * 1e-3) / 1e9
+    out = {"kernel_path": ctx.last_path(), "value": leg.n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "kernel": KERNEL_NAMES["f32_tiled"], "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg}}
+    if cpu is not None:
+        idx, ref = cpu
+        g = leg.d_out.cpu().numpy()[idx]
+        nan_same = bool(np.array_equal(np.isnan(g), np.isnan(ref)))
+        out["parity"] = {"points": int(len(idx)), "invalid_mask_equal": nan_same,
+                         "max_abs_diff_px": float(np.nanmax(np.abs(g - ref))) if np.isfinite(ref).any() else 0.0,
+                         "bit_identical": bool(nan_same and np.array_equal(np.nan_to_num(g).view(np.uint32), np.nan_to_num(ref).view(np.uint32)))}
+    return out
 
 
 def program_leg(api, ctx, xy):
@@ -219,7 +327,8 @@ def program_leg(api, ctx, xy):
     return {"what": "mimc3_vmap: CP offset + 32 matcher passes (ocw 7/15/30/40 x raw/ddx/ddy/laplacian x fwd/swapped) + postprocess",
             "seconds": best, "grid_points": int(x.shape[0]), "cp_status": int(out["cp_status"]), "cp_offset": list(out["offset_cp"]),
             "finite_frac": float(np.isfinite(out["vx"]).mean()) if ok else None,
-            "reference_program_seconds_same_box": 323.6, "reference_source": "profiles/round1/vmap_fullsize_C2.json (256 host threads)"}
+            "reference": "the unmodified reference program on the same inputs is timed by tests/fullsize/vmap_fullsize.py "
+                         "(profiles/round*/vmap_fullsize_*.json); not re-timed here (minutes of CPU)"}
 
 
 def qm_leg(torch, api, synth, ctx, dev, case, sweeps, check, reps=5):
@@ -298,15 +407,13 @@ def cpu_baseline(case, xy, piv_off, piv_uv, gpu_out, sample):
     base = {"value": len(idx) / dt, "unit": "grid-points/s", "cores": cores, "kind": kind,
             "sample": f"{len(idx)} of {n} grid points (evenly spaced), one matcher pass, {dt:.1f} s, OpenMP dynamic"}
     par = {"points": int(len(idx)), "invalid_mask_equal": nan_same, "max_abs_diff_px": diff, "bit_identical": bits}
-    return base, par
+    return base, par, (idx, cpu)
 
 
 def _subset_match(o, case, xy, piv_off, piv_uv, idx):
-    cnt = (piv_off[idx + 1] - piv_off[idx]).astype(np.int64)
-    off = np.zeros(len(idx) + 1, np.int64)
-    np.cumsum(cnt, out=off[1:])
-    sel = np.concatenate([np.arange(piv_off[i], piv_off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, np.int64)
-    return o.match(case.i0, case.i1, xy[idx], case.offset, off, piv_uv[sel], case.ocw)
+    from mimc3_amd import shard
+    sxy, off, uv = shard.gather_problem(xy, piv_off, piv_uv, idx)
+    return o.match(case.i0, case.i1, sxy, case.offset, off, uv, case.ocw)
 
 
 if __name__ == "__main__":

@@ -96,6 +96,8 @@ extern "C" int mimc3_postprocess_dev(mimc3_ctx *ctx, const float *d_dp, int32_t 
     auto take = [&](size_t b) { View v{cur}; cur += b; return v; };
     View mvn = take(b_mvn), ncl = take(b_n), kmax = take(256), dpf = take(b_n), dx = take(b_n), dy = take(b_n), r1 = take(b_r1),
          r2 = take(b_r2), w1 = take(b_w1), w2 = take(b_w2);
+    HIP_TRY(hipMemcpyAsync(r1.p, ruv1.data(), 8 * (size_t)nn1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r2.p, ruv2.data(), 8 * (size_t)nn2, hipMemcpyHostToDevice, s));
     RC_TRY(mimc3_cluster_candidates_dev(ctx, d_dp, ndp, N, K, mvn.as<float>(), ncl.as<int32_t>(), kmax.as<int32_t>(), s));   // :904
     RC_TRY(mimc3_get_dpf0_dev(ctx, mvn.as<float>(), ncl.as<int32_t>(), N, K, 0.6f, dpf.as<int32_t>(), s));                    // :912
     int32_t sweeps = 0;

@@ -80,17 +80,30 @@ def all_gather_blocks(local, per, world):
     return full
 
 
+class Unpermute:
+    """Index tensors (built once per partition) that take all-gathered padded blocks back to grid order."""
+
+    def __init__(self, order, start, per, device):
+        import torch
+        world = len(start) - 1
+        src = np.concatenate([r * per + np.arange(int(start[r + 1] - start[r]), dtype=np.int64) for r in range(world)])
+        self.src = torch.from_numpy(src).to(device)
+        self.dst = torch.from_numpy(np.asarray(order, np.int64)).to(device)
+        self.n = len(order)
+
+    def __call__(self, gathered):
+        """gathered [world, per, ...] -> [n, ...] in grid order (padding rows dropped)."""
+        import torch
+        flat = gathered.reshape((gathered.shape[0] * gathered.shape[1],) + tuple(gathered.shape[2:]))
+        out = torch.empty((self.n,) + tuple(flat.shape[1:]), dtype=flat.dtype, device=flat.device)
+        out[self.dst] = flat[self.src]
+        return out
+
+
 def unpermute(gathered, order, start, n):
     """gathered [world, per, ...] + the partition -> the grid-ordered tensor [n, ...] (padding rows dropped)."""
-    import torch
-    world, per = gathered.shape[0], gathered.shape[1]
-    out = torch.empty((n,) + tuple(gathered.shape[2:]), dtype=gathered.dtype, device=gathered.device)
-    for r in range(world):
-        k = int(start[r + 1] - start[r])
-        if k:
-            idx = torch.from_numpy(np.asarray(order[start[r]:start[r + 1]], np.int64)).to(gathered.device)
-            out[idx] = gathered[r, :k]
-    return out
+    assert n == len(order)
+    return Unpermute(order, start, gathered.shape[1], gathered.device)(gathered)
 
 
 def all_gather_field(local, n, per, world, rank):
