@@ -97,6 +97,8 @@ __device__ __forceinline__ double dpp_add_f64(double x, int ctrl_sel)
 struct PxU8 {
     static constexpr int BPP = 1, G = 4, LOG2G = 2;
     static constexpr bool SRC16 = false;
+    static constexpr bool INTEGER = true;                     // exact integer sums: null corrections may be applied in any order
+    __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *p; }
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -178,6 +180,8 @@ __device__ __forceinline__ unsigned long long dpp_add_u64(unsigned long long x, 
 struct PxU16 {
     static constexpr int BPP = 2, G = 2, LOG2G = 1;
     static constexpr bool SRC16 = false;
+    static constexpr bool INTEGER = true;
+    __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const unsigned short *>(p); }
     typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
@@ -275,6 +279,8 @@ struct PxU8o : PxU8 {
 struct PxF32 {
     static constexpr int BPP = 4, G = 1, LOG2G = 0;
     static constexpr bool SRC16 = false;
+    static constexpr bool INTEGER = false;
+    __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const uint32_t *>(p); }
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
     __device__ static __forceinline__ uint32_t lowmask(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -348,7 +354,15 @@ struct PxCfg {
     static constexpr uint32_t LAST01 = LASTFF & 0x01010101u;
     static constexpr int CPR = 64 / LPC;                     // cells per evaluation round
     static constexpr bool OPQ = LPC_ >= 64;                  // big chips: keep chip-derived masks out of registers (see PxU8::task)
+    // Big chips with exact integer sums: a cell whose box (or whose chip) holds null pixels is evaluated as the FAST body
+    // (3 dot products per dword) plus CORRECTIONS summed over short lists of the null pixels -- window nulls take chip
+    // values out of n, sx, sxx; chip nulls take window values out of sy, syy -- instead of the six-sum GENERAL body
+    // (17 VALU per dword).  One wave evaluates one cell, so 64 lanes share the list walk.
+    static constexpr bool SPARSE = (LPC_ >= 64) && P::INTEGER;
+    static constexpr int CPITCH = 4 * GPR;                   // LDS chip copy: bytes per row
 };
+static constexpr int kLwCap = 1024;    // window-null list entries (x | y << 16); more -> the point falls back to GENERAL
+static constexpr int kLcCap = 512;     // chip-null list entries
 
 struct U8Point {
     int dx2, dy2, Dx2, Dy2, csx, csy, ncell;
@@ -363,10 +377,10 @@ template <class C, int MODE>
 __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
-                                          const int (&toff)[C::TT > 0 ? C::TT : 1])
+                                          const int (&toff)[C::TT > 0 ? C::TT : 1],
+                                          AccT<typename C::P::Sum> acc = AccT<typename C::P::Sum>{0, 0, 0, 0, 0, 0})
 {
     typedef typename C::P P;
-    AccT<typename P::Sum> acc{0, 0, 0, 0, 0, 0};
     const int X = pt.sh + cx;                                       // pixel offset of the box inside the LDS row
     const uint32_t s = (uint32_t)((X & (P::G - 1)) * P::BPP);       // byte phase inside the first dword
     const unsigned char *base = W + cy * pt.PW + 4 * (X >> P::LOG2G);
@@ -399,7 +413,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
     return acc;
 }
 
-static constexpr int kStatW = 12;      // diagnostics: 8 phase clocks + cell counts (clean, dirty, evaluate calls)
+static constexpr int kStatW = 16;      // diagnostics: 8 phase clocks + cell counts (clean, dirty, evaluate calls) + null-list use
 static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in LDS before the f64 finish
 
 #define MIMC3_STAMP(i)                                                                         \
@@ -485,7 +499,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // [4] null pixels in the window, [5..8] their bounding box (x0,x1,y0,y1), [9] driver decision
     int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // behind the sums
     // ([11..14]: PxU8o only -- min/max of the non-null window and chip pixels)
-    if (tid < 16) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14) ? -1 : 0);
+    // [16] window-null list length, [17] chip-null list length, [18] a list overflowed (SPARSE configs)
+    if (tid < 32) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14) ? -1 : 0);
+    unsigned char *CH = smem + p.lds_off_chip;                             // SPARSE: chip copy [CW][CPITCH]
+    uint32_t *Lw = reinterpret_cast<uint32_t *>(smem + p.lds_off_lw);      // SPARSE: null pixels of the window (x | y << 16)
+    uint32_t *Lc = reinterpret_cast<uint32_t *>(smem + p.lds_off_lc);      // SPARSE: null pixels of the chip's row-task rows
+    (void)CH; (void)Lw; (void)Lc;
     __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
     auto lookup = [&](int cell) __attribute__((always_inline)) -> float {
@@ -565,6 +584,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             if (nz) {
                 const int x0 = P::G * c - pt.sh;
                 nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); nby0 = min(nby0, r); nby1 = max(nby1, r);
+                if constexpr (C::SPARSE) {
+                    int at = atomicAdd(&qcnt[16], nz);
+                    if (at + nz > kLwCap) qcnt[18] = 1;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < P::G; k++) {
+                            const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
+                            if ((keep & pm) && !(v & pm)) Lw[at++] = (uint32_t)(x0 + k) | ((uint32_t)r << 16);
+                        }
+                    }
+                }
             }
         }
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
@@ -629,6 +659,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 a = P::sanitize(a, pt.thr);
                 A[i][j] = a;
                 P::chip_acc(SX, SXX, a);
+                if constexpr (C::SPARSE) {
+                    if (wave == 0 && rowok) {
+                        const int rr = l + C::LPC * i;
+                        *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;
+                        const int nzc = P::nexcl(a, pff, pt.thr);
+                        if (nzc) {
+                            int at = atomicAdd(&qcnt[17], nzc);
+                            if (at + nzc > kLcCap) qcnt[18] = 1;
+                            else {
+#pragma unroll
+                                for (int k = 0; k < P::G; k++) {
+                                    const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
+                                    if ((pff & pm) && !(a & pm)) Lc[at++] = (uint32_t)(P::G * j + k) | ((uint32_t)rr << 16);
+                                }
+                            }
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
@@ -645,6 +693,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
             P::chip_acc(SX, SXX, a);
+            if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
+                if (wave == 0 && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
+            }
         }
         bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
         SX = P::template gsum<C::LPC>(SX); SXX = P::template gsum<C::LPC>(SXX);
@@ -654,6 +705,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     MIMC3_STAMP(1)
     if (p.debug_stop == 2) { if (tid == 0) p.out[3 * (size_t)gidx] = (float)((uint32_t)P::bits(SX) + (uint32_t)P::bits(SXX) + bad_chip + A[0][0] + AT[0]); return; }
     __syncthreads();   // single-wave workgroup: orders the LDS stores above before the reads below
+    const bool sparse_on = C::SPARSE && qcnt[18] == 0;     // both null lists complete
+    const int nLw = sparse_on ? qcnt[16] : 0, nLc = sparse_on ? qcnt[17] : 0;
+    (void)nLw; (void)nLc;
+    if (p.stats && tid == 0) {
+        p.stats[kStatW * (size_t)blockIdx.x + 11] += sparse_on ? 1 : 0;
+        p.stats[kStatW * (size_t)blockIdx.x + 12] += (unsigned)nLw; p.stats[kStatW * (size_t)blockIdx.x + 13] += (unsigned)nLc;
+    }
 
     // ---- validity (a6, :635) --------------------------------------------------------------------
     {
@@ -755,14 +813,76 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00000101u;
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 AccT<Sum> acc;
-                if (mode == M_FAST) {
-                    acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff);
-                } else if (mode == M_CHIPNULL) {
-                    acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, AT, toff);
-                } else {
-                    acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, AT, toff);
+                bool done = false;
+                if constexpr (C::SPARSE) {
+                    // one wave = one cell.  Unless the box touches the never-written last row/column (T4: a whole row of
+                    // nulls) the cell is the FAST body plus corrections over the null lists.
+                    const bool dirty = (mode == M_GENERAL) && p.debug_stop != 100;
+                    if (p.debug_stop == 100 || (sparse_on && !(dirty && (cx == pt.csx - 2 || cy == pt.csy - 2)))) {
+                        AccT<Sum> a0{0, 0, 0, 0, 0, 0};
+                        uint32_t cn = 0;
+                        Sum csx = 0, csxx = 0;
+                        // The list walks are latency chains (list entry -> address -> pixel): four entries per lane are kept in
+                        // flight, out-of-box entries read pixel 0 and are masked afterwards.
+                        if (dirty) {                                   // window nulls inside the box: their chip pixels leave n, sx, sxx
+                            for (int i0 = l; i0 < nLw; i0 += 4 * C::LPC) {
+                                uint32_t e[4], av[4];
+                                bool in[4];
+#pragma unroll
+                                for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLw) ? Lw[i0 + k * C::LPC] : 0xffffffffu;
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    const int ddx = (int)(e[k] & 0xffffu) - cx, ddy = (int)(e[k] >> 16) - cy;
+                                    in[k] = (unsigned)ddx < (unsigned)CW && (unsigned)ddy < (unsigned)CW;
+                                    av[k] = P::px_at(CH + (in[k] ? ddy * C::CPITCH + ddx * P::BPP : 0));
+                                }
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    const uint32_t a1 = in[k] ? av[k] : 0u;
+                                    cn += a1 ? 1u : 0u; csx += a1; csxx += (Sum)a1 * a1;
+                                }
+                            }
+                        }
+                        Sum csy = 0, csyy = 0;
+                        const unsigned char *Wc = W + cy * pt.PW + (pt.sh + cx) * P::BPP;
+                        for (int i0 = l; i0 < (p.debug_stop == 100 ? 0 : nLc); i0 += 4 * C::LPC) {  // chip nulls (row-task rows): the window pixels under them leave sy, syy
+                            uint32_t e[4], bv[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLc) ? Lc[i0 + k * C::LPC] : 0xffffffffu;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const bool ok = e[k] != 0xffffffffu;
+                                bv[k] = P::px_at(Wc + (ok ? (int)(e[k] >> 16) * pt.PW + (int)(e[k] & 0xffffu) * P::BPP : 0));
+                                bv[k] = ok ? bv[k] : 0u;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { csy += bv[k]; csyy += (Sum)bv[k] * bv[k]; }
+                        }
+                        // 32-bit sums: fold the correction into the lane's partial sum (modulo 2^32, the reduced total is exact);
+                        // the u16 policy's lanes accumulate 32 bits inside a 64-bit sum, so there the correction is reduced apart
+                        constexpr bool kFold = sizeof(Sum) == 4;
+                        if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
+                        acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff, a0);
+                        if (!kFold && nLc > 0) { acc.sy -= P::template gsum<C::LPC>(csy); acc.syy -= P::template gsum<C::LPC>(csyy); }
+                        acc.n = NV; acc.sx = SX; acc.sxx = SXX;
+                        if (dirty) {
+                            acc.n -= group_sum<C::LPC>(cn);
+                            acc.sx -= P::template gsum<C::LPC>(csx);
+                            acc.sxx -= P::template gsum<C::LPC>(csxx);
+                        }
+                        done = true;
+                    }
                 }
-                if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
+                if (!done) {
+                    if (mode == M_FAST) {
+                        acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff);
+                    } else if (mode == M_CHIPNULL) {
+                        acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, AT, toff);
+                    } else {
+                        acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, AT, toff);
+                    }
+                    if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
+                }
                 if (on && l == 0) {
                     Store *sp = sums + 6 * slot;
                     sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
@@ -1150,8 +1270,13 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     off = (off + 15) & ~(size_t)15; r.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
     off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 4 * (size_t)r.lds_list_cap;
-    off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 64;
+    off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 128;
     off = (off + 15) & ~(size_t)15; r.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
+    if (C::SPARSE) {
+        off = (off + 15) & ~(size_t)15; r.lds_off_chip = (int)off; off += (size_t)C::CPITCH * C::CW;
+        off = (off + 15) & ~(size_t)15; r.lds_off_lw = (int)off; off += 4 * (size_t)kLwCap;
+        off = (off + 15) & ~(size_t)15; r.lds_off_lc = (int)off; off += 4 * (size_t)kLcCap;
+    }
     off = (off + 15) & ~(size_t)15;
     return off;
 }
@@ -1205,8 +1330,8 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
         fprintf(stderr, "[mimc3 u8 stats] cycles/point: stage %.0f chip %.0f request %.0f eval+fit %.0f spec %.0f pre-replay %.0f replay-loop %.0f publish %.0f\n",
                 (double)h[0] / a.N, (double)h[1] / a.N, (double)h[2] / a.N, (double)h[3] / a.N, (double)h[4] / a.N,
                 (double)h[5] / a.N, (double)h[6] / a.N, (double)h[7] / a.N);
-        fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches\n",
-                (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N);
+        fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches; null lists in use %.3f of points, %.0f window / %.0f chip entries per point\n",
+                (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N, (double)h[11] / a.N, (double)h[12] / a.N, (double)h[13] / a.N);
     }
     return hipGetLastError();
 }

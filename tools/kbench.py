@@ -13,6 +13,8 @@ import sys
 import time
 
 import numpy as np
+import torch   # BEFORE mimc3_amd.api: the process must hold ONE HIP runtime (torch bundles its own libamdhip64; loaded first,
+               # it also satisfies libmimc3_hip.so's dependency -- the other order gives two runtimes and "no HIP device")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +25,6 @@ FULL = ["u8_16", "u8_7", "u8_15", "u8_30", "u8_40", "ddx_30", "ddx_40", "lap_30"
 
 
 def main():
-    import torch
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     check = 0
     if "--check" in sys.argv:
@@ -33,7 +34,9 @@ def main():
     reps = int(os.environ.get("KBENCH_REPS", "5"))
     c = synth.make_case("C2")
     H, W = c.i0.shape
+    torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream()
     orc = None
     if check:
         from oracle import oracle as o
@@ -59,7 +62,6 @@ def main():
         if check:
             cpu_imgs[v] = ctx.get_images(H, W)
 
-    stream = torch.cuda.current_stream()
     piv_cache = {}
     for name in names:
         kind, ocw = name.split("_")
