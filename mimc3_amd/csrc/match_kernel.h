@@ -53,10 +53,9 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     const int32_t *point_list, *point_count;   // list mode: workgroup b handles point_list[b], b < *point_count (nullptr = all N points)
     int32_t *fail_list, *fail_count;           // PxU8o only: points whose chip or window does not fit a local 8-bit range
     // LDS carve, filled by the launcher
-    int32_t lds_pw, lds_off_val, lds_off_ncc, lds_off_req, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
+    int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
-    int32_t cache_cap, map_u16;     // NCC cache slots per point; cell->slot map element width
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off
     int32_t dry_run;                // launcher only: compute the LDS carve and return hipSuccess / hipErrorInvalidValue (does not fit

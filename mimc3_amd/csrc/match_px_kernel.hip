@@ -373,7 +373,7 @@ struct U8Point {
 
 // One evaluation round: lane group g (LPC lanes) evaluates the cell whose chip origin in window
 // coordinates is (cx, cy) (== compact cell coordinates).  Returns group-reduced sums in every lane.
-template <class C, int MODE>
+template <class C, int MODE, bool REDUCE = true>
 __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
@@ -406,6 +406,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
         const uint32_t bw = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], s) : rp[0];
         P::template task<MODE, C::OPQ>(acc, AT[k], 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from AT[k] itself
     }
+    if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE == M_GENERAL) {
         acc.n = group_sum<C::LPC>(acc.n); acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx);
@@ -473,32 +474,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
-    // NCC cache: a cell that has been requested owns slot map[cell]-1 of nccv[] (0 = never requested)
-    unsigned char *cmap8 = smem + p.lds_off_val;                          // [csy][csx] u8  (cap <= 255)
-    uint16_t *cmap16 = reinterpret_cast<uint16_t *>(smem + p.lds_off_val);//           or u16
-    float *nccv = reinterpret_cast<float *>(smem + p.lds_off_ncc);        // [cap]
-    uint32_t *reqb = reinterpret_cast<uint32_t *>(smem + p.lds_off_req);  // requested bits [ncell]
+    // NCC cache: one f32 per compact cell, read with ONE LDS access (the climb's lookups are latency chains):
+    // kUnknown = never asked for, kWanted = queued for evaluation, anything else = the NCC (NaN is a value)
+    float *val = reinterpret_cast<float *>(smem + p.lds_off_val);         // [csy][csx]
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits, rows padded to words
-    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // packed cells (slot<<16|cy<<8|cx): clean boxes from the front, dirty from the back
+    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // cells queued for evaluation (cy<<8|cx): clean boxes from the front, dirty from the back
     typedef typename P::Store Store;
     Store *sums = reinterpret_cast<Store *>(smem + p.lds_off_sums);        // [kSumBatch][6] reduced sums
     int32_t *pivs = reinterpret_cast<int32_t *>(smem + p.lds_off_piv);    // [npiv][2]
-    const int lcap = p.lds_list_cap, cap = p.cache_cap;
-    const bool map16 = p.map_u16 != 0;
+    const int lcap = p.lds_list_cap;
 
-    {
-        const int nmapw = map16 ? ((pt.ncell + 1) >> 1) : ((pt.ncell + 3) >> 2);
-        uint32_t *mw = reinterpret_cast<uint32_t *>(smem + p.lds_off_val);
-        for (int i = tid; i < nmapw; i += NT) mw[i] = 0u;
-        for (int i = tid; i < ((pt.ncell + 31) >> 5); i += NT) reqb[i] = 0u;
-    }
     const int vpitch = ((pt.csx + 31) >> 5) << 5;          // visited bits: one row = whole 32-bit words
     for (int i = tid; i < ((pt.csy * vpitch) >> 5); i += NT) vis[i] = 0u;
     for (int i = tid; i < 2 * npiv; i += NT) pivs[i] = pv_g[i];
-    // control words: [0] clean queued, [1] dirty queued, [2] cache slots used, [3] cache overflow,
+    // control words: [0] queue fill, clean | dirty << 16, [3] queue overflow,
     // [4] null pixels in the window, [5..8] their bounding box (x0,x1,y0,y1), [9] driver decision
     int32_t *qcnt = reinterpret_cast<int32_t *>(sums + 6 * kSumBatch);   // behind the sums
     // ([11..14]: PxU8o only -- min/max of the non-null window and chip pixels)
+    for (int i = tid; i < 6 * kSumBatch; i += NT) sums[i] = 0;             // parking slots of the atomically parked sums
     // [16] window-null list length, [17] chip-null list length, [18] a list overflowed (SPARSE configs)
     if (tid < 32) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14) ? -1 : 0);
     unsigned char *CH = smem + p.lds_off_chip;                             // SPARSE: chip copy [CW][CPITCH]
@@ -507,10 +500,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     (void)CH; (void)Lw; (void)Lc;
     __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
-    auto lookup = [&](int cell) __attribute__((always_inline)) -> float {
-        const int sl = map16 ? (int)cmap16[cell] : (int)cmap8[cell];
-        return sl ? nccv[sl - 1] : kUnknown;
-    };
+    for (int i = tid; i < pt.ncell; i += NT) val[i] = kUnknown;
+    auto vslot = [&](int cx, int cy) __attribute__((always_inline)) -> float * { return &val[cy * pt.csx + cx]; };
+    auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float { return val[cy * pt.csx + cx]; };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
     int ka = 0, kb = 0;                                      // PxU8o: per-point offsets of chip and window (0 otherwise)
@@ -737,60 +729,53 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         return (cx > nbx1) || (cx + CW - 1 < nbx0) || (cy > nby1) || (cy + CW - 1 < nby0);
     };
 
-    // ---- request queue: a cell is requested at most once (CAS on its cache slot); clean boxes are
-    //      queued from the front of `list`, dirty boxes from the back ------------------------------
+    // ---- request queue: a cell is requested at most once (compare-and-swap kUnknown -> kWanted on its cache word); clean
+    //      boxes are queued from the front of `list`, dirty boxes from the back; ONE packed counter (clean | dirty << 16)
+    //      so that a request costs two dependent LDS round trips.  A batch that outgrows the queue hands the point over
+    //      to the general kernel (qcnt[3]).
+    const uint32_t kUnknownBits = __float_as_uint(kUnknown), kWantedBits = __float_as_uint(kWanted);
     auto request = [&](int cx, int cy) __attribute__((always_inline)) {
-        const int cell = cy * pt.csx + cx;
-        const uint32_t bit = 1u << (cell & 31);
-        if (atomicOr(&reqb[cell >> 5], bit) & bit) return;                 // somebody already asked for it
-        const int slot = atomicAdd(&qcnt[2], 1);
-        if (slot >= cap) { qcnt[3] = 1; return; }                          // cache full: the point is handed to the general kernel
-        if (map16) cmap16[cell] = (uint16_t)(slot + 1); else cmap8[cell] = (unsigned char)(slot + 1);
-        nccv[slot] = kWanted;
-        const uint32_t packed = ((uint32_t)slot << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
-        if (box_clean(cx, cy)) list[atomicAdd(&qcnt[0], 1)] = packed;
-        else list[lcap - 1 - atomicAdd(&qcnt[1], 1)] = packed;
+        float *slotp = vslot(cx, cy);
+        if (atomicCAS(reinterpret_cast<uint32_t *>(slotp), kUnknownBits, kWantedBits) != kUnknownBits) return;   // asked for or known already
+        const bool cl = box_clean(cx, cy);
+        const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], cl ? 1 : (1 << 16));
+        const int ia = (int)(q & 0xffffu), ib = (int)(q >> 16);
+        if (ia + ib + 1 > lcap) { qcnt[3] = 1; return; }
+        const uint32_t packed = ((uint32_t)cy << 8) | (uint32_t)cx;
+        if (cl) list[ia] = packed; else list[lcap - 1 - ib] = packed;
     };
     auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
         return !(pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1);
     };
-    // request the whole 3x3 around compact cell (cx0, cy0) with THREE dependent LDS round trips instead
-    // of up to 27: the nine "requested" bit-sets are issued together, one counter bump reserves the
-    // cache slots of the cells this lane won, one bump per class reserves the queue entries
+    // request the whole 3x3 around compact cell (cx0, cy0): the nine compare-and-swaps are issued together, one bump of
+    // the packed counter reserves the queue entries of the cells this lane won
     auto request9 = [&](int cx0, int cy0) __attribute__((always_inline)) {
         uint32_t old[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
-            const int cell = (cy0 + (j % 3 - 1)) * pt.csx + cx0 + (j / 3 - 1);
-            old[j] = atomicOr(&reqb[cell >> 5], 1u << (cell & 31));
+            float *slotp = vslot(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1));
+            old[j] = atomicCAS(reinterpret_cast<uint32_t *>(slotp), kUnknownBits, kWantedBits);
         }
         uint32_t won = 0;
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const int cell = (cy0 + (j % 3 - 1)) * pt.csx + cx0 + (j / 3 - 1);
-            if (!((old[j] >> (cell & 31)) & 1u)) won |= 1u << j;
-        }
+        for (int j = 0; j < 9; j++)
+            if (old[j] == kUnknownBits) won |= 1u << j;
         if (!won) return;
-        const int nw = __popc(won);
-        int slot = atomicAdd(&qcnt[2], nw);
-        if (slot + nw > cap) { qcnt[3] = 1; return; }                       // cache full: the point goes to the general kernel
         uint32_t cl = 0;
 #pragma unroll
         for (int j = 0; j < 9; j++)
             if (((won >> j) & 1u) && box_clean(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1))) cl |= 1u << j;
         const uint32_t wa = won & cl, wb = won & ~cl;
-        int ia = wa ? atomicAdd(&qcnt[0], __popc(wa)) : 0;
-        int ib = wb ? atomicAdd(&qcnt[1], __popc(wb)) : 0;
+        const int na = __popc(wa), nb = __popc(wb);
+        const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], na | (nb << 16));
+        int ia = (int)(q & 0xffffu), ib = (int)(q >> 16);
+        if (ia + ib + na + nb > lcap) { qcnt[3] = 1; return; }
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             if (!((won >> j) & 1u)) continue;
             const int cx = cx0 + (j / 3 - 1), cy = cy0 + (j % 3 - 1);
-            const int cell = cy * pt.csx + cx;
-            if (map16) cmap16[cell] = (uint16_t)(slot + 1); else cmap8[cell] = (unsigned char)(slot + 1);
-            nccv[slot] = kWanted;
-            const uint32_t packed = ((uint32_t)slot << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+            const uint32_t packed = ((uint32_t)cy << 8) | (uint32_t)cx;
             if ((wa >> j) & 1u) list[ia++] = packed; else list[lcap - 1 - ib++] = packed;
-            slot++;
         }
     };
     // round 0 = the certain set: every pivot whose start passes the boundary test scans its whole 3x3
@@ -804,7 +789,27 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     MIMC3_STAMP(2)
 
     // evaluates the `cnt` cells ids[0], ids[dir], ids[2*dir], ... in mode `mode`; NCC -> val[]
+    //
+    // How a cell's sums reach the f64 finish.  Groups of 16 lanes (small chips) reduce entirely with DPP row operations and
+    // lane 0 stores.  Groups of 32 / 64 lanes would need ds_bpermute stages (an LDS round trip each, six sums in a row =
+    // a long serial tail per cell): the integer policies instead reduce each 16-lane row with DPP and let the row leaders
+    // ADD their partial sums into the cell's parking slot with LDS atomics (no return value: nothing waits on them; integer
+    // adds commute, so the result is exact and deterministic).  The slots are zero between batches.
+    constexpr bool kAPark = (C::LPC >= 32) && P::INTEGER;
     auto evaluate = [&](const uint32_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
+        const bool dirty_list = (mode == M_GENERAL);
+        // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
+        uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
+        if constexpr (C::SPARSE) {
+            if (sparse_on && cnt > 0) {
+                if (dirty_list) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (l + k * C::LPC < nLw) ew[k] = Lw[l + k * C::LPC];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) if (l + k * C::LPC < nLc) ec[k] = Lc[l + k * C::LPC];
+            }
+        }
         for (int b0 = 0; b0 < cnt; b0 += kSumBatch) {
             const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
             for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
@@ -813,85 +818,110 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const uint32_t pk = on ? ids[dir * (b0 + slot)] : 0x00000101u;
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 AccT<Sum> acc;
+                bool six = dirty_list;                                // all six sums are cell-specific (else n, sx, sxx are the point's constants)
                 bool done = false;
                 if constexpr (C::SPARSE) {
                     // one wave = one cell.  Unless the box touches the never-written last row/column (T4: a whole row of
                     // nulls) the cell is the FAST body plus corrections over the null lists.
-                    const bool dirty = (mode == M_GENERAL) && p.debug_stop != 100;
-                    if (p.debug_stop == 100 || (sparse_on && !(dirty && (cx == pt.csx - 2 || cy == pt.csy - 2)))) {
+                    if (sparse_on && !(dirty_list && (cx == pt.csx - 2 || cy == pt.csy - 2))) {
                         AccT<Sum> a0{0, 0, 0, 0, 0, 0};
                         uint32_t cn = 0;
-                        Sum csx = 0, csxx = 0;
-                        // The list walks are latency chains (list entry -> address -> pixel): four entries per lane are kept in
-                        // flight, out-of-box entries read pixel 0 and are masked afterwards.
-                        if (dirty) {                                   // window nulls inside the box: their chip pixels leave n, sx, sxx
-                            for (int i0 = l; i0 < nLw; i0 += 4 * C::LPC) {
-                                uint32_t e[4], av[4];
-                                bool in[4];
+                        Sum csx = 0, csxx = 0, csy = 0, csyy = 0;
+                        auto corr_w = [&](const uint32_t (&e)[4]) __attribute__((always_inline)) {
+                            uint32_t av[4];
+                            bool in[4];
 #pragma unroll
-                                for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLw) ? Lw[i0 + k * C::LPC] : 0xffffffffu;
-#pragma unroll
-                                for (int k = 0; k < 4; k++) {
-                                    const int ddx = (int)(e[k] & 0xffffu) - cx, ddy = (int)(e[k] >> 16) - cy;
-                                    in[k] = (unsigned)ddx < (unsigned)CW && (unsigned)ddy < (unsigned)CW;
-                                    av[k] = P::px_at(CH + (in[k] ? ddy * C::CPITCH + ddx * P::BPP : 0));
-                                }
-#pragma unroll
-                                for (int k = 0; k < 4; k++) {
-                                    const uint32_t a1 = in[k] ? av[k] : 0u;
-                                    cn += a1 ? 1u : 0u; csx += a1; csxx += (Sum)a1 * a1;
-                                }
+                            for (int k = 0; k < 4; k++) {          // window nulls inside the box: their chip pixels leave n, sx, sxx
+                                const int ddx = (int)(e[k] & 0xffffu) - cx, ddy = (int)(e[k] >> 16) - cy;
+                                in[k] = (unsigned)ddx < (unsigned)CW && (unsigned)ddy < (unsigned)CW;
+                                av[k] = P::px_at(CH + (in[k] ? (int)__umul24(ddy, C::CPITCH) + ddx * P::BPP : 0));
                             }
-                        }
-                        Sum csy = 0, csyy = 0;
-                        const unsigned char *Wc = W + cy * pt.PW + (pt.sh + cx) * P::BPP;
-                        for (int i0 = l; i0 < (p.debug_stop == 100 ? 0 : nLc); i0 += 4 * C::LPC) {  // chip nulls (row-task rows): the window pixels under them leave sy, syy
-                            uint32_t e[4], bv[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLc) ? Lc[i0 + k * C::LPC] : 0xffffffffu;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
+                                const uint32_t a1 = in[k] ? av[k] : 0u;
+                                cn += a1 ? 1u : 0u; csx += a1; csxx += (Sum)__umul24(a1, a1);
+                            }
+                        };
+                        const unsigned char *Wc = W + cy * pt.PW + (pt.sh + cx) * P::BPP;
+                        auto corr_c = [&](const uint32_t (&e)[2]) __attribute__((always_inline)) {
+                            uint32_t bv[2];
+#pragma unroll
+                            for (int k = 0; k < 2; k++) {          // chip nulls (row-task rows): the window pixels under them leave sy, syy
                                 const bool ok = e[k] != 0xffffffffu;
-                                bv[k] = P::px_at(Wc + (ok ? (int)(e[k] >> 16) * pt.PW + (int)(e[k] & 0xffffu) * P::BPP : 0));
+                                bv[k] = P::px_at(Wc + (ok ? (int)__umul24(e[k] >> 16, pt.PW) + (int)(e[k] & 0xffffu) * P::BPP : 0));
                                 bv[k] = ok ? bv[k] : 0u;
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; k++) { csy += bv[k]; csyy += (Sum)bv[k] * bv[k]; }
+                            for (int k = 0; k < 2; k++) { csy += bv[k]; csyy += (Sum)__umul24(bv[k], bv[k]); }
+                        };
+                        if (dirty_list) {
+                            corr_w(ew);
+                            for (int i0 = l + 4 * C::LPC; i0 < nLw; i0 += 4 * C::LPC) {       // long lists: the rest from LDS
+                                uint32_t e[4];
+#pragma unroll
+                                for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLw) ? Lw[i0 + k * C::LPC] : 0xffffffffu;
+                                corr_w(e);
+                            }
                         }
-                        // 32-bit sums: fold the correction into the lane's partial sum (modulo 2^32, the reduced total is exact);
-                        // the u16 policy's lanes accumulate 32 bits inside a 64-bit sum, so there the correction is reduced apart
+                        if (nLc > 0) {
+                            corr_c(ec);
+                            for (int i0 = l + 2 * C::LPC; i0 < nLc; i0 += 2 * C::LPC) {
+                                uint32_t e[2];
+#pragma unroll
+                                for (int k = 0; k < 2; k++) e[k] = (i0 + k * C::LPC < nLc) ? Lc[i0 + k * C::LPC] : 0xffffffffu;
+                                corr_c(e);
+                            }
+                        }
+                        // lane-local, modulo 2^32 / 2^64: the reduced totals are exact.  (The u16 policy's lanes accumulate
+                        // 32 bits inside a 64-bit sum, so there the correction is subtracted after the body.)
                         constexpr bool kFold = sizeof(Sum) == 4;
                         if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
-                        acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff, a0);
-                        if (!kFold && nLc > 0) { acc.sy -= P::template gsum<C::LPC>(csy); acc.syy -= P::template gsum<C::LPC>(csyy); }
-                        acc.n = NV; acc.sx = SX; acc.sxx = SXX;
-                        if (dirty) {
-                            acc.n -= group_sum<C::LPC>(cn);
-                            acc.sx -= P::template gsum<C::LPC>(csx);
-                            acc.sxx -= P::template gsum<C::LPC>(csxx);
-                        }
+                        acc = eval_round<C, M_FAST, false>(W, pt, cx, cy, l, A, AT, toff, a0);
+                        if (!kFold) { acc.sy -= csy; acc.syy -= csyy; }
+                        acc.n = 0u - cn; acc.sx = (Sum)0 - csx; acc.sxx = (Sum)0 - csxx;      // + the point's constants, in the finish
                         done = true;
+                    } else {
+                        six = dirty_list;
                     }
                 }
                 if (!done) {
-                    if (mode == M_FAST) {
-                        acc = eval_round<C, M_FAST>(W, pt, cx, cy, l, A, AT, toff);
-                    } else if (mode == M_CHIPNULL) {
-                        acc = eval_round<C, M_CHIPNULL>(W, pt, cx, cy, l, A, AT, toff);
-                    } else {
-                        acc = eval_round<C, M_GENERAL>(W, pt, cx, cy, l, A, AT, toff);
-                    }
-                    if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
+                    if (mode == M_FAST) acc = eval_round<C, M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
+                    else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
+                    else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
                 }
-                if (on && l == 0) {
-                    Store *sp = sums + 6 * slot;
-                    sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
+                Store *sp = sums + 6 * slot;
+                if constexpr (kAPark) {
+                    // 16-lane row sums (DPP), then the row leaders add into the slot
+                    const Sum rsy = P::template gsum<16>(acc.sy), rsyy = P::template gsum<16>(acc.syy), rsxy = P::template gsum<16>(acc.sxy);
+                    const bool lead = on && (l & 15) == 0;
+                    if (lead) { atomicAdd(&sp[2], P::bits(rsy)); atomicAdd(&sp[4], P::bits(rsyy)); atomicAdd(&sp[5], P::bits(rsxy)); }
+                    if (six) {
+                        const uint32_t rn = group_sum<16>(acc.n);
+                        const Sum rsx = P::template gsum<16>(acc.sx), rsxx = P::template gsum<16>(acc.sxx);
+                        if (lead) { atomicAdd(&sp[0], (Store)rn); atomicAdd(&sp[1], P::bits(rsx)); atomicAdd(&sp[3], P::bits(rsxx)); }
+                    }
+                } else {
+                    if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
+                    if (on && l == 0) {
+                        sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
+                    }
                 }
             }
             __syncthreads();
             if (tid < nb) {
                 const uint32_t pk = ids[dir * (b0 + tid)];
-                nccv[pk >> 16] = P::ncc(sums + 6 * tid, sc_chip, sc_win, ka, kb);
+                const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
+                Store *sp = sums + 6 * tid;
+                Store v[6] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
+                if constexpr (kAPark) {
+                    // cells whose n, sx, sxx are the point's constants (minus the corrections that were added above)
+                    const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(cx == pt.csx - 2 || cy == pt.csy - 2));
+                    if (!dense) { v[0] += (Store)NV; v[1] += P::bits(SX); v[3] += P::bits(SXX); }
+                    if (C::SPARSE) v[0] = (Store)(uint32_t)v[0];          // n travels as a 32-bit count (corrections wrap modulo 2^32)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) sp[k] = 0;                 // the slot is empty for the next batch
+                }
+                *vslot(cx, cy) = P::ncc(v, sc_chip, sc_win, ka, kb);
             }
             __syncthreads();
         }
@@ -917,6 +947,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     unsigned long long traj = 0ull;
     int nsc = 0;                                     // scans recorded so far
     bool replay_generic = false;
+    bool cut = false;                                // this lane's speculation was stopped before its climb ended
     // wave-uniform state of the reference's loops (:691-753)
     int k = 0, pu = 0, pvv = 0, du = 0, dv = 0, newncc = 0;
     bool fresh = true;
@@ -929,13 +960,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             return;
         }
         {   // evaluate everything queued, then empty the queue (the only call site of `evaluate`)
-            const int nA = qcnt[0], nB = qcnt[1];
+            const int nA = qcnt[0] & 0xffff, nB = (int)((uint32_t)qcnt[0] >> 16);
             if (p.stats && tid == 0) {
                 p.stats[kStatW * (size_t)blockIdx.x + 8] += nA; p.stats[kStatW * (size_t)blockIdx.x + 9] += nB;
                 p.stats[kStatW * (size_t)blockIdx.x + 10] += (nA + nB) ? 1 : 0;
             }
             __syncthreads();
-            if (tid < 2) qcnt[tid] = 0;
+            if (tid == 0) qcnt[0] = 0;
             evaluate(list, 1, nA, clean_mode);
             evaluate(list + lcap - 1, -1, nB, M_GENERAL);
             __syncthreads();
@@ -950,13 +981,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // pivots count too); when it runs into unknown cells it queues them, plus the 3x3 one step
             // further in the direction it just moved (lookahead: straight climbs advance 2 scans per batch)
             int ldu = 0, ldv = 0;
-            while (alive && nsc < kSpecRounds) {
+            while (alive && !cut && nsc < kSpecRounds) {
                 int mv = -1;
                 float sm = smax;
                 bool known = true;
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
-                    const float v = lookup((sv + (j % 3 - 1) - OCW) * pt.csx + (su + (j / 3 - 1) - OCW));
+                    const float v = lookup(su + (j / 3 - 1) - OCW, sv + (j % 3 - 1) - OCW);
                     known = known && !(v >= 2.5f);                  // 3.0 / 4.0 = not evaluated yet (NaN is a value)
                     if (v > sm) { sm = v; mv = j; }                 // NaN never wins (:736)
                 }
@@ -969,18 +1000,22 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 nsc++;
                 alive = moved && inside(su, sv);
             }
-            if (alive && nsc < kSpecRounds) {
+            if (alive && !cut && nsc < kSpecRounds) {
                 request9(su - OCW, sv - OCW);
                 for (int la = 1; la <= kLookahead; la++)              // straight-line lookahead along the last move
-                    if ((ldu | ldv) != 0 && inside(su + la * ldu, sv + la * ldv)) request9(su + la * ldu - OCW, sv + la * ldv - OCW);
+                    if ((ldu | ldv) != 0 && inside(su + la * ldu, sv + la * ldv))
+                        request9(su + la * ldu - OCW, sv + la * ldv - OCW);
             }
             stage++;
             MIMC3_STAMP(4)
-            const bool more = __any(alive && nsc < kSpecRounds);
-            if (more && qcnt[0] + qcnt[1] != 0) return 0;          // evaluate the queued cells, then scan on
-            replay_generic = (npiv > 64) || __any(alive);           // a climb longer than kSpecRounds scans: generic replay
+            const bool more = __any(alive && !cut && nsc < kSpecRounds);
+            if (more && qcnt[0] != 0) return 0;                      // evaluate the queued cells, then scan on
+            // A lane that is still alive here had its speculation CUT (kSpecRounds scans, or the edge of the cache band).  Real
+            // climbs are usually much shorter than speculative ones (the visited state ends them), so the exact replay runs
+            // on the recorded prefixes first; only if a cut pivot really consumes its whole prefix the generic loops take over.
+            replay_generic = (npiv > 64);
             stage = kSpecRounds;
-            if (qcnt[0] + qcnt[1] != 0) return 0;                   // (generic case) evaluate what was queued first
+            if (qcnt[0] != 0) return 0;                             // evaluate what was queued first
         }
         if (!replay_generic) {
             // ---- exact replay from the recorded trajectories.  Every scan's move and running maximum
@@ -1028,6 +1063,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
                 if (lane == kk) T = Tk;
             }
+            if (__any(alive && T == nsc)) {          // a cut pivot really went through its whole recorded prefix: the generic loops decide
+                replay_generic = true;
+                if (!regmask)                        // the large-grid form marked its scans in LDS: start over from a clean visited set
+                    for (int i = lane; i < ((pt.csy * vpitch) >> 5); i += 64) vis[i] = 0u;
+            } else {
             if (regmask && lane < pt.csy) {   // publish the visited rows for the fit (csx <= 64: vpitch is 32 or 64)
                 vis[(lane * vpitch) >> 5] = vlo;
                 if (vpitch > 32) vis[((lane * vpitch) >> 5) + 1] = vhi;
@@ -1042,7 +1082,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
             }
             const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
-            const float fmax = upd ? lookup((fv - OCW) * pt.csx + (fu - OCW)) : -2.0f;
+            const float fmax = upd ? lookup(fu - OCW, fv - OCW) : -2.0f;
             float bv = (lane < npiv) ? fmax : -__builtin_inff();
             int bi = lane;
             argmax_row16(bv, bi);
@@ -1059,6 +1099,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
             }
             return 1;
+            }
         }
         // ---- exact hill climb (resumable), generic form: the reference's sequential loops ----------
         bool finished = false;
@@ -1079,8 +1120,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const bool act = lane < 9;
             const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
             const int cx = pu + c1 - OCW, cy = pvv + c2 - OCW;
-            const int cidx = act ? cy * pt.csx + cx : 0;
-            const float v = lookup(cidx);
+            const float v = act ? lookup(cx, cy) : kUnknown;
             const int vb = act ? cy * vpitch + cx : 0;
             const bool unvis = act && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
             const bool missing = unvis && (v == kUnknown || v == kWanted);
@@ -1108,6 +1148,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         __syncthreads();
         if (qcnt[9]) break;
     }
+    if (qcnt[3]) {                                       // the last climb step left the cache band
+        if (tid == 0) p.ovf_list[atomicAdd(p.ovf_count, 1)] = gidx;
+        return;
+    }
     MIMC3_STAMP(3)
     if (p.debug_stop == 6) { if (tid == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
     // ---- 3x3 quadratic fit (:757-788) ----------------------------------------------------------
@@ -1117,9 +1161,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const int cidx = (peak_v - 1 + r - OCW) * pt.csx + (peak_u - 1 + c - OCW);
                 const int vb = (peak_v - 1 + r - OCW) * vpitch + (peak_u - 1 + c - OCW);
-                n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? lookup(cidx) : -2.0f;
+                n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? lookup(peak_u - 1 + c - OCW, peak_v - 1 + r - OCW) : -2.0f;   // visited = scanned = inside the band
             }
         double cp0, cp1, cp2, cp3, cp4;
         cp0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
@@ -1258,16 +1301,12 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
     static const int slack_env = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 0;   // tests shrink it to force the overflow path
     const int slack = slack_env ? slack_env : (max_npiv <= 20 ? 64 : 12 * max_npiv);
-    int cap = 9 * max_npiv + slack;
+    int cap = 9 * max_npiv + slack;                     // cells one batch may queue (the certain set is the largest batch)
     if (cap > cells) cap = cells;
     if (cap < 16) cap = 16;
-    r.cache_cap = cap;
-    r.map_u16 = cap > 255 ? 1 : 0;
     r.lds_list_cap = cap + 16;
     size_t off = (size_t)r.lds_pw * Dy2;
-    off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += (size_t)cells * (r.map_u16 ? 2 : 1);
-    off = (off + 15) & ~(size_t)15; r.lds_off_ncc = (int)off; off += 4 * (size_t)cap;
-    off = (off + 15) & ~(size_t)15; r.lds_off_req = (int)off; off += 4 * (size_t)((cells + 31) >> 5);
+    off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += 4 * (size_t)cells;
     off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 4 * (size_t)r.lds_list_cap;
     off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 128;
@@ -1330,6 +1369,11 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
         fprintf(stderr, "[mimc3 u8 stats] cycles/point: stage %.0f chip %.0f request %.0f eval+fit %.0f spec %.0f pre-replay %.0f replay-loop %.0f publish %.0f\n",
                 (double)h[0] / a.N, (double)h[1] / a.N, (double)h[2] / a.N, (double)h[3] / a.N, (double)h[4] / a.N,
                 (double)h[5] / a.N, (double)h[6] / a.N, (double)h[7] / a.N);
+        {
+            int32_t novf = 0;
+            if (a.ovf_count) (void)hipMemcpy(&novf, a.ovf_count, sizeof(novf), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mimc3 u8 stats] points handed to the general kernel: %d of %d\n", novf, a.N);
+        }
         fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches; null lists in use %.3f of points, %.0f window / %.0f chip entries per point\n",
                 (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N, (double)h[11] / a.N, (double)h[12] / a.N, (double)h[13] / a.N);
     }
