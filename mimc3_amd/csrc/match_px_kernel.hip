@@ -107,6 +107,9 @@ struct PxU8 {
     __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float) { return npx(keep) - __popc(nz80(v) >> 7); }
     __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return nbad(v, keep, thr); }
     __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float) { return a; }     // nulls are already 0
+    // may the kept bytes of v hold a null?  (zero-byte detector; a borrow can raise a false alarm next to a real zero byte,
+    // never a miss: the caller then counts exactly)
+    __device__ static __forceinline__ bool maybe_excl(uint32_t v, uint32_t keep, float) { return ((v - 0x01010101u) & ~v & 0x80808080u & keep) != 0u; }
     __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a) { sx = dot4(a, 0x01010101u, sx); sxx = dot4(a, a, sxx); }
     template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t pad01, uint32_t padff, bool static_pad, uint32_t bw, float)
@@ -189,6 +192,7 @@ struct PxU16 {
     __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float) { return npx(keep) - __popc(nz8000(v) >> 15); }   // null <=> q == 0
     __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return nbad(v, keep, thr); }
     __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float) { return a; }
+    __device__ static __forceinline__ bool maybe_excl(uint32_t v, uint32_t keep, float) { return ((v - 0x00010001u) & ~v & 0x80008000u & keep) != 0u; }
     __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a)
     {
         sx = dot2(a, 0x00010001u, (uint32_t)sx); sxx = dot2(a, a, (uint32_t)sxx);
@@ -288,6 +292,7 @@ struct PxF32 {
     __device__ static __forceinline__ int nbad(uint32_t v, uint32_t keep, float thr) { return (keep && __uint_as_float(v) < thr) ? 1 : 0; }       // :622
     __device__ static __forceinline__ int nexcl(uint32_t v, uint32_t keep, float thr) { return (keep && !(__uint_as_float(v) >= thr)) ? 1 : 0; }  // :723 (NaN too)
     __device__ static __forceinline__ uint32_t sanitize(uint32_t a, float thr) { return (__uint_as_float(a) >= thr) ? a : 0u; }  // excluded chip pixels -> 0.0
+    __device__ static __forceinline__ bool maybe_excl(uint32_t v, uint32_t keep, float thr) { return keep && !(__uint_as_float(v) >= thr); }   // covers "< thr" (:622) too
     __device__ static __forceinline__ void chip_acc(Sum &sx, Sum &sxx, uint32_t a)
     {
         const float f = __uint_as_float(a);
@@ -511,11 +516,21 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     {
         const int wcols = 2 * pt.dx2, wrows = 2 * pt.dy2;                 // written area (:869-886)
         const int nd = (pt.sh + wcols + P::G - 1) >> P::LOG2G;            // aligned dwords per row
-        const uint32_t inv = (uint32_t)(0xffffffffu / (uint32_t)nd) + 1u; // exact idx/nd for idx*nd < 2^32
-        const int tot = wrows * nd;
+        // every thread keeps ONE dword column c and walks down the rows r0, r0 + rstep, ...: column masks, addresses and the
+        // LDS offset are loop invariants / plain increments (one division per thread instead of one per dword)
+        // (a row wider than the workgroup -- long corridors on one-wave configs -- takes several column sweeps: cstep)
+        const int rstep = NT / nd > 0 ? NT / nd : 1;                     // rows covered per sweep
+        const int c_first = tid % nd, r0 = tid / nd, cstep = nd <= NT ? nd : NT;
+        const bool col_on = r0 < rstep;                                   // the last NT - rstep*nd threads have no column
         const int lastp = (pt.sh + wcols) & (P::G - 1);                   // valid pixels in the last dword (0 = all)
         const uint32_t first_ff = ~P::lowmask(pt.sh);
         const uint32_t last_ff = lastp ? P::lowmask(lastp) : 0xffffffffu;
+        auto col_keep = [&](int c) __attribute__((always_inline)) -> uint32_t {
+            uint32_t k = 0xffffffffu;
+            if (c == 0) k &= first_ff;
+            if (c == nd - 1) k &= last_ff;
+            return k;
+        };
         const uint32_t *gbase = reinterpret_cast<const uint32_t *>(win_pl + ((size_t)wv0 * Wp + (wu0 - pt.sh)) * P::BPP);
         const int gpitch = (Wp * P::BPP) >> 2;
         // PxU8o: the source planes are u16; four pixels = one aligned uint2
@@ -525,14 +540,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         if constexpr (P::SRC16) {
             // pass 1: local range of the window and of the chip; a point that does not fit 8 bits goes to the u16 kernel
             int mn = 1 << 20, mx = -1;
-            for (int idx = tid; idx < tot; idx += NT) {
-                const int r = (int)__umulhi((uint32_t)idx, inv);
-                const int c = idx - r * nd;
-                uint32_t keep = 0xffffffffu;
-                if (c == 0) keep &= first_ff;
-                if (c == nd - 1) keep &= last_ff;
-                PxU8o::range4(gbase16[(size_t)r * gpitch16 + c], keep, mn, mx);
-            }
+            if (col_on)
+                for (int c = c_first; c < nd; c += cstep) {
+                    const uint32_t keep = col_keep(c);
+                    for (int r = r0; r < wrows; r += rstep) PxU8o::range4(gbase16[(size_t)r * gpitch16 + c], keep, mn, mx);
+                }
             int cmn = 1 << 20, cmx = -1;
             {
                 const unsigned short *c16 = reinterpret_cast<const unsigned short *>(chip_pl);
@@ -559,35 +571,61 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             kb = mx < mn ? 0 : mn - 1;
             ka = cmx < cmn ? 0 : cmn - 1;
         }
-        for (int idx = tid; idx < tot; idx += NT) {
-            const int r = (int)__umulhi((uint32_t)idx, inv);
-            const int c = idx - r * nd;
-            uint32_t v;
-            if constexpr (P::SRC16) v = PxU8o::pack(gbase16[(size_t)r * gpitch16 + c], kb);
-            else v = gbase[(size_t)r * gpitch + c];
-            uint32_t keep = 0xffffffffu;
-            if (c == 0) keep &= first_ff;
-            if (c == nd - 1) keep &= last_ff;
-            v &= keep;                                                    // pixels outside the written columns -> 0 (covers T4 column)
-            *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = v;
-            bad_win += P::nbad(v, keep, pt.thr);
-            const int nz = P::nexcl(v, keep, pt.thr);
-            exc_win += nz;
-            if (nz) {
-                const int x0 = P::G * c - pt.sh;
-                nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); nby0 = min(nby0, r); nby1 = max(nby1, r);
-                if constexpr (C::SPARSE) {
-                    int at = atomicAdd(&qcnt[16], nz);
-                    if (at + nz > kLwCap) qcnt[18] = 1;
-                    else {
+        // The row walk is a chain of global loads: eight rows are fetched before any of them is used (one memory latency per
+        // eight rows instead of one per row), and the rare null handling runs after the batch on the values in registers.
+        if (col_on)
+        for (int c = c_first; c < nd; c += cstep) {
+            const uint32_t keep = col_keep(c);
+            const int x0 = P::G * c - pt.sh;                              // window column of the dword's first pixel
+            bool hit = false;                                             // this column holds excluded pixels (x range of the null box)
+            constexpr int KB = 8;
+            for (int rb = r0; rb < wrows; rb += KB * rstep) {
+                uint32_t v[KB];
+                [[maybe_unused]] uint2 v16[KB];
 #pragma unroll
-                        for (int k = 0; k < P::G; k++) {
-                            const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
-                            if ((keep & pm) && !(v & pm)) Lw[at++] = (uint32_t)(x0 + k) | ((uint32_t)r << 16);
+                for (int k = 0; k < KB; k++) {
+                    const int r = rb + k * rstep;
+                    const int rl = r < wrows ? r : rb;                    // rows past the end re-read the batch's first row (discarded)
+                    if constexpr (P::SRC16) v16[k] = gbase16[(size_t)rl * gpitch16 + c];
+                    else v[k] = gbase[(size_t)rl * gpitch + c];
+                }
+                bool susp = false;
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const int r = rb + k * rstep;
+                    if constexpr (P::SRC16) v[k] = PxU8o::pack(v16[k], kb);
+                    v[k] &= keep;                                         // pixels outside the written columns -> 0 (covers T4 column)
+                    if (r < wrows) {
+                        *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = v[k];
+                        susp = susp || P::maybe_excl(v[k], keep, pt.thr);
+                    }
+                }
+                if (susp) {                                               // rare: count exactly, bound, list
+#pragma unroll
+                    for (int k = 0; k < KB; k++) {
+                        const int r = rb + k * rstep;
+                        if (r >= wrows || !P::maybe_excl(v[k], keep, pt.thr)) continue;
+                        bad_win += P::nbad(v[k], keep, pt.thr);
+                        const int nz = P::nexcl(v[k], keep, pt.thr);
+                        exc_win += nz;
+                        if (!nz) continue;
+                        hit = true;
+                        nby0 = min(nby0, r); nby1 = max(nby1, r);
+                        if constexpr (C::SPARSE) {
+                            int at = atomicAdd(&qcnt[16], nz);
+                            if (at + nz > kLwCap) qcnt[18] = 1;
+                            else {
+#pragma unroll
+                                for (int q = 0; q < P::G; q++) {
+                                    const uint32_t pm = P::lowmask(1) << (8 * P::BPP * q);
+                                    if ((keep & pm) && !(v[k] & pm)) Lw[at++] = (uint32_t)(x0 + q) | ((uint32_t)r << 16);
+                                }
+                            }
                         }
                     }
                 }
             }
+            if (hit) { nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); }
         }
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
         // after each row's last written dword (read by the sliding loads of the right-most cells)
@@ -620,6 +658,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     uint32_t A[RFA][GPR], AT[TTA];
     int toff[TTA];
     int bad_chip = 0, exc_chip = 0;
+    bool chip_susp = false;                                  // some chip dword of this lane may hold a null (integer policies: counted afterwards)
     Sum SX = 0, SXX = 0;
     {
         const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
@@ -647,27 +686,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
                 const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
                 a &= pff;
-                bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
-                a = P::sanitize(a, pt.thr);
+                if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);    // the exact counts are taken afterwards, and only then
+                else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
                 A[i][j] = a;
                 P::chip_acc(SX, SXX, a);
                 if constexpr (C::SPARSE) {
-                    if (wave == 0 && rowok) {
-                        const int rr = l + C::LPC * i;
-                        *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;
-                        const int nzc = P::nexcl(a, pff, pt.thr);
-                        if (nzc) {
-                            int at = atomicAdd(&qcnt[17], nzc);
-                            if (at + nzc > kLcCap) qcnt[18] = 1;
-                            else {
-#pragma unroll
-                                for (int k = 0; k < P::G; k++) {
-                                    const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
-                                    if ((pff & pm) && !(a & pm)) Lc[at++] = (uint32_t)(P::G * j + k) | ((uint32_t)rr << 16);
-                                }
-                            }
-                        }
-                    }
+                    if (wave == 0 && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;
                 }
             }
         }
@@ -680,13 +704,49 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             uint32_t a = (P::G > 1) ? alignb(chip_dword(rr, j + (P::G > 1 ? 1 : 0)), g0, sa) : g0;
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
-            bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr);
-            a = P::sanitize(a, pt.thr);
+            if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);
+            else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
             P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
                 if (wave == 0 && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
+            }
+        }
+        if (P::INTEGER && chip_susp) {                        // rare: the lane's chip dwords again, counted exactly (and listed)
+#pragma unroll
+            for (int i = 0; i < C::RF; i++) {
+                const bool rowok = !C::SHORT || l < C::CW;
+#pragma unroll
+                for (int j = 0; j < GPR; j++) {
+                    const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
+                    const uint32_t a = A[i][j];
+                    if (!P::maybe_excl(a, pff, pt.thr)) continue;
+                    bad_chip += P::nbad(a, pff, pt.thr);
+                    const int nzc = P::nexcl(a, pff, pt.thr);
+                    exc_chip += nzc;
+                    if constexpr (C::SPARSE) {
+                        if (wave == 0 && rowok && nzc) {
+                            int at = atomicAdd(&qcnt[17], nzc);
+                            if (at + nzc > kLcCap) qcnt[18] = 1;
+                            else {
+#pragma unroll
+                                for (int k = 0; k < P::G; k++) {
+                                    const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
+                                    if ((pff & pm) && !(a & pm)) Lc[at++] = (uint32_t)(P::G * j + k) | ((uint32_t)(l + C::LPC * i) << 16);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < C::TT; k++) {
+                const int tt = l + C::LPC * k;
+                const bool on = tt < C::REM * GPR;
+                const int j = on ? tt % GPR : 0;
+                const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
+                if (P::maybe_excl(AT[k], pff, pt.thr)) { bad_chip += P::nbad(AT[k], pff, pt.thr); exc_chip += P::nexcl(AT[k], pff, pt.thr); }
             }
         }
         bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
