@@ -483,7 +483,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // kUnknown = never asked for, kWanted = queued for evaluation, anything else = the NCC (NaN is a value)
     float *val = reinterpret_cast<float *>(smem + p.lds_off_val);         // [csy][csx]
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + p.lds_off_vis);   // visited bits, rows padded to words
-    uint32_t *list = reinterpret_cast<uint32_t *>(smem + p.lds_off_list); // cells queued for evaluation (cy<<8|cx): clean boxes from the front, dirty from the back
+    uint16_t *list = reinterpret_cast<uint16_t *>(smem + p.lds_off_list); // cells queued for evaluation (cy<<8|cx): clean boxes from the front, dirty from the back
     typedef typename P::Store Store;
     Store *sums = reinterpret_cast<Store *>(smem + p.lds_off_sums);        // [kSumBatch][6] reduced sums
     int32_t *pivs = reinterpret_cast<int32_t *>(smem + p.lds_off_piv);    // [npiv][2]
@@ -505,9 +505,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     (void)CH; (void)Lw; (void)Lc;
     __syncthreads();
     // NCC of a compact cell, kUnknown when it has not been evaluated
-    for (int i = tid; i < pt.ncell; i += NT) val[i] = kUnknown;
-    auto vslot = [&](int cx, int cy) __attribute__((always_inline)) -> float * { return &val[cy * pt.csx + cx]; };
-    auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float { return val[cy * pt.csx + cx]; };
+    // scan centres pass the boundary test (:703), i.e. lie in [2, cs-3]; their 3x3 and the fit's 3x3 reach [1, cs-2]: the
+    // outermost ring of compact cells is never touched and has no cache word
+    const int vpitchc = pt.csx - 2;
+    for (int i = tid; i < vpitchc * (pt.csy - 2); i += NT) val[i] = kUnknown;
+    auto vslot = [&](int cx, int cy) __attribute__((always_inline)) -> float * { return &val[(cy - 1) * vpitchc + (cx - 1)]; };
+    auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float { return val[(cy - 1) * vpitchc + (cx - 1)]; };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
     int ka = 0, kb = 0;                                      // PxU8o: per-point offsets of chip and window (0 otherwise)
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], cl ? 1 : (1 << 16));
         const int ia = (int)(q & 0xffffu), ib = (int)(q >> 16);
         if (ia + ib + 1 > lcap) { qcnt[3] = 1; return; }
-        const uint32_t packed = ((uint32_t)cy << 8) | (uint32_t)cx;
+        const uint16_t packed = (uint16_t)((cy << 8) | cx);
         if (cl) list[ia] = packed; else list[lcap - 1 - ib] = packed;
     };
     auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         for (int j = 0; j < 9; j++) {
             if (!((won >> j) & 1u)) continue;
             const int cx = cx0 + (j / 3 - 1), cy = cy0 + (j % 3 - 1);
-            const uint32_t packed = ((uint32_t)cy << 8) | (uint32_t)cx;
+            const uint16_t packed = (uint16_t)((cy << 8) | cx);
             if ((wa >> j) & 1u) list[ia++] = packed; else list[lcap - 1 - ib++] = packed;
         }
     };
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // ADD their partial sums into the cell's parking slot with LDS atomics (no return value: nothing waits on them; integer
     // adds commute, so the result is exact and deterministic).  The slots are zero between batches.
     constexpr bool kAPark = (C::LPC >= 32) && P::INTEGER;
-    auto evaluate = [&](const uint32_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
+    auto evaluate = [&](const uint16_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
         const bool dirty_list = (mode == M_GENERAL);
         // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
         uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
@@ -1360,15 +1363,15 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
     static const int slack_env = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 0;   // tests shrink it to force the overflow path
-    const int slack = slack_env ? slack_env : (max_npiv <= 20 ? 64 : 12 * max_npiv);
-    int cap = 9 * max_npiv + slack;                     // cells one batch may queue (the certain set is the largest batch)
+    // the queue empties every batch; the certain set (<= 9 cells per pivot) is the largest batch
+    int cap = 9 * max_npiv + (slack_env ? slack_env : (max_npiv <= 20 ? 16 : 4 * max_npiv));
     if (cap > cells) cap = cells;
     if (cap < 16) cap = 16;
     r.lds_list_cap = cap + 16;
     size_t off = (size_t)r.lds_pw * Dy2;
-    off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += 4 * (size_t)cells;
+    off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += 4 * (size_t)(csx - 2) * (Dy2 - 2 * C::OCW - 1);   // (csx-2) x (csy-2) cache words
     off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
-    off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 4 * (size_t)r.lds_list_cap;
+    off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 2 * (size_t)r.lds_list_cap;
     off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 128;
     off = (off + 15) & ~(size_t)15; r.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
     if (C::SPARSE) {
@@ -1398,6 +1401,8 @@ template <class C>
 static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     const size_t off = px_layout<C>(&a, max_abs_u, max_abs_v, max_npiv);
+    static const bool lds_dbg = getenv("MIMC3_LDS_DEBUG") != nullptr;
+    if (lds_dbg && !a.dry_run) fprintf(stderr, "[mimc3 lds] ocw %d: %zu bytes per workgroup\n", C::OCW, off);
     if (off > kLdsCapBytes) return hipErrorInvalidValue;   // nothing was launched: callers probe with dry_run and take the general kernel instead
     if (a.dry_run) return hipSuccess;
     px_set_lds_attr<C>();
@@ -1418,7 +1423,8 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     }
     a.stats = want_stats ? d_stats : nullptr;
     if (want_stats) (void)hipMemsetAsync(d_stats, 0, kStatW * sizeof(unsigned long long) * (size_t)nb, stream);
-    hipLaunchKernelGGL(match_ncc_dlc_px<C>, dim3(nb), dim3(C::NT), off, stream, a);
+    static const size_t lds_pad = getenv("MIMC3_LDS_PAD") ? (size_t)atoi(getenv("MIMC3_LDS_PAD")) : 0;   // tuning: find the occupancy steps (LDS is granted in 256-byte units)
+    hipLaunchKernelGGL(match_ncc_dlc_px<C>, dim3(nb), dim3(C::NT), off + lds_pad, stream, a);
     if (want_stats) {
         (void)hipStreamSynchronize(stream);
         unsigned long long *hh = (unsigned long long *)malloc(kStatW * sizeof(unsigned long long) * (size_t)nb);
@@ -1468,7 +1474,7 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 16: return launch_cfg<PxCfg<PxU16, 16, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);   // 216 VGPRs, no scratch: 44.7 ms vs 49.5 at 3 waves/SIMD with 192 B of spills
     default: return hipErrorInvalidValue;
     }
 }
