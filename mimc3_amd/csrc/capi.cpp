@@ -87,6 +87,10 @@ struct mimc3_ctx {
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     DevBuf slot[16];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
+    int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
+    DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
+    int32_t win_half = 0;               // internal (CP stage): > 0 = the next matcher calls use a full (2*win_half+1)^2 search area
+    mimc3_ctx *cp_child = nullptr;      // CP stage: a context of its own for the chip atlas (planes, kernel selection)
     DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
     DevBuf raw_dn;                      // raw 8/16-bit DN as uploaded (mimc3_ctx_set_images_u8/_u16), widened on the device
 };
@@ -211,6 +215,9 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
     c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
+    if (c->cp_child) { mimc3_ctx_destroy(c->cp_child); c->cp_child = nullptr; }
+    for (auto &b : c->ovf_alt) b.release();
+    for (auto &b : c->fail_alt) b.release();
     c->raw_dn.release(); c->cellws.release();
     for (auto &b : c->slot) b.release();
     for (auto &pp : c->pin) if (pp) (void)hipHostFree(pp);
@@ -410,9 +417,10 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     a.piv_uv = d_piv_uv; a.piv_off = d_piv_off; a.ocw = ocw; a.swap = swap ? 1 : 0;
     a.thr = min_dn_threshold();
     a.out = d_out;
+    a.win_half = c->win_half;
     hipStream_t s = static_cast<hipStream_t>(stream);
     {   // the general kernel (the last resort of every policy) keeps the cell grid in a global workspace when it outgrows LDS
-        const size_t ws = mimc3::match_f32_workspace_bytes(ocw, max_abs_piv_u, max_abs_piv_v, max_npiv, 0);
+        const size_t ws = mimc3::match_f32_workspace_bytes(ocw, max_abs_piv_u, max_abs_piv_v, max_npiv, c->win_half);
         if (ws) {
             HIP_TRY(c->cellws.reserve(ws));
             a.cell_ws = static_cast<unsigned char *>(c->cellws.p); a.cell_ws_bytes = c->cellws.cap;
@@ -427,7 +435,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     typedef hipError_t (*px_launcher)(mimc3::MatchU8Args, int, int, int, hipStream_t);
     auto fits = [&](px_launcher fn) {
         mimc3::MatchU8Args probe{};
-        probe.ocw = ocw; probe.dry_run = 1;
+        probe.ocw = ocw; probe.dry_run = 1; probe.win_half = c->win_half;
         return fn(probe, max_abs_piv_u, max_abs_piv_v, max_npiv, nullptr) == hipSuccess;
     };
     const bool px_ok = mimc3::match_u8_supported(ocw, reach_u, reach_v);
@@ -454,11 +462,14 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W; u.thr = a.thr;
         u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
         u.piv_uv = d_piv_uv; u.piv_off = d_piv_off; u.ocw = ocw; u.swap = swap ? 1 : 0; u.out = d_out;
+        u.win_half = c->win_half;
         // points whose per-point NCC cache overflows (very long climbs) are appended to a device list and
         // redone by the general kernel right behind, in list mode: no host round trip
-        HIP_TRY(c->ovf.reserve(sizeof(int32_t) * ((size_t)N + 1)));
-        HIP_TRY(hipMemsetAsync(c->ovf.p, 0, sizeof(int32_t), s));
-        u.ovf_count = static_cast<int32_t *>(c->ovf.p);
+        DevBuf &ovf = c->lane ? c->ovf_alt[c->lane - 1] : c->ovf;
+        DevBuf &failb = c->lane ? c->fail_alt[c->lane - 1] : c->fail;
+        HIP_TRY(ovf.reserve(sizeof(int32_t) * ((size_t)N + 1)));
+        HIP_TRY(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
+        u.ovf_count = static_cast<int32_t *>(ovf.p);
         u.ovf_list = u.ovf_count + 1;
         if (want_u8) {
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
@@ -469,9 +480,9 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
             u.scale0 = 1.0 / (double)(1 << c->shift0); u.scale1 = 1.0 / (double)(1 << c->shift1);
             if (c->u8o_ok && c->u16_ok && c->path_mode == 0) {
                 // u8 machinery through per-point offsets first; what does not fit is redone by the u16 kernel in list mode
-                HIP_TRY(c->fail.reserve(sizeof(int32_t) * ((size_t)N + 1)));
-                HIP_TRY(hipMemsetAsync(c->fail.p, 0, sizeof(int32_t), s));
-                u.fail_count = static_cast<int32_t *>(c->fail.p);
+                HIP_TRY(failb.reserve(sizeof(int32_t) * ((size_t)N + 1)));
+                HIP_TRY(hipMemsetAsync(failb.p, 0, sizeof(int32_t), s));
+                u.fail_count = static_cast<int32_t *>(failb.p);
                 u.fail_list = u.fail_count + 1;
                 e = mimc3::launch_match_u8o(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
                 if (e == hipSuccess) {
@@ -1041,32 +1052,36 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                 HIP_TRY(mimc3::launch_cp_shift_copy(d_t0, d_mn0, n, ocw_chip, d_a0, s));
                 HIP_TRY(mimc3::launch_cp_shift_copy(d_t1, d_mn1, n, ocw_chip, d_a1, s));
             }
-            // the four matches of this image variant (2 chip sizes x forward/swapped) are a few hundred workgroups each:
-            // they run side by side on four streams, forked from and joined back into the context's stream
-            HIP_TRY(hipEventRecord(c->ev_side[3], s));
+            // the four matches of this image variant (2 chip sizes x forward/swapped): the chip atlas is an image pair of its
+            // own (tile t = candidate t), handed to a child context that classifies it (8-bit / scaled integers / floats) and
+            // runs the same tiled kernels as the DLC passes -- full-square search area (win_half), the 21x21 pivot set as a
+            // replicated CSR
+            HIP_TRY(hipStreamSynchronize(s));                                      // the atlas is complete
+            if (!c->cp_child) RC_TRY(mimc3_ctx_create(c->device, &c->cp_child));
+            mimc3_ctx *ch = c->cp_child;
+            ch->path_mode = c->path_mode;
+            RC_TRY(mimc3_ctx_set_images_dev(ch, d_a0, d_a1, n * cs, cs));
+            ch->win_half = ocw_chip;
+            // a match is a few hundred workgroups (latency-bound on its own): the four run side by side on four streams,
+            // each with its own overflow lists
             for (int c3 = 1; c3 < 3; c3++) {                                       // :330-384
                 const int ocw = p->vec_ocw[c3];
                 const int32_t slot = (c3 - 1) * 8 + (kk + 1) * 2;
+                const int reach = ocw_chip - ocw - 2;
                 for (int sw = 0; sw < 2; sw++) {
-                    const int lane_id = (c3 - 1) * 2 + sw;                         // 0..3; lane 0 = the context's own stream
-                    hipStream_t ms = lane_id == 0 ? s : c->side[lane_id - 1];
-                    if (lane_id) HIP_TRY(hipStreamWaitEvent(ms, c->ev_side[3], 0));
-                    mimc3::MatchArgs a{};
-                    a.i0 = d_a0; a.i1 = d_a1; a.H = n * cs; a.W = cs;
-                    a.xyuvav = d_xy; a.N = n; a.off_u = 0; a.off_v = 0;
-                    a.piv_uv = d_piv; a.piv_off = d_poff; a.ocw = ocw; a.swap = sw; a.win_half = ocw_chip;
-                    a.thr = min_dn_threshold();
-                    a.out = d_dp + (size_t)(slot + sw) * n * 3;
-                    const int reach = ocw_chip - ocw - 2;
-                    hipError_t e = mimc3::launch_match_f32(a, reach, reach, npiv, ms);
-                    if (e != hipSuccess) return mimc3::hip_fail(e, "control-point match launch");
-                    if (sw) HIP_TRY(mimc3::launch_negate_uv(a.out, n, ms));         // :376-377
-                    if (lane_id) {
-                        HIP_TRY(hipEventRecord(c->ev_side[lane_id - 1], ms));
-                        HIP_TRY(hipStreamWaitEvent(s, c->ev_side[lane_id - 1], 0)); // the next variant overwrites the atlas
-                    }
+                    const int lane_id = (c3 - 1) * 2 + sw;                         // 0..3
+                    hipStream_t ms = lane_id == 0 ? ch->stream : c->side[lane_id - 1];
+                    float *o = d_dp + (size_t)(slot + sw) * n * 3;
+                    ch->lane = lane_id;
+                    int rc = mimc3_match_ncc_dlc_dev(ch, d_xy, n, 0, 0, d_piv, d_poff, npiv, reach, reach, ocw, sw, o, ms);
+                    ch->lane = 0;
+                    if (rc) { ch->win_half = 0; return rc; }
+                    if (sw) HIP_TRY(mimc3::launch_negate_uv(o, n, ms));             // :376-377
                 }
             }
+            ch->win_half = 0;
+            HIP_TRY(hipStreamSynchronize(ch->stream));                             // the next variant overwrites the atlas
+            for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
         }
         // ---- clusters of the 16 matches; those holding >= 60 % vote with their mean (:392-413)
         mimc3::ClusterArgs ca{};

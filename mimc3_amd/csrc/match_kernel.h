@@ -48,6 +48,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     const int32_t *piv_uv;
     const int64_t *piv_off;
     int32_t ocw, swap;
+    int32_t win_half;               // 0: DLC window (|last pivot|+ocw+2, last row/column empty); > 0: full (2*win_half+1)^2 search area (CP stage)
     float *out;
     int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
     const int32_t *point_list, *point_count;   // list mode: workgroup b handles point_list[b], b < *point_count (nullptr = all N points)

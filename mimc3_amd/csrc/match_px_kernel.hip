@@ -299,10 +299,15 @@ struct PxF32 {
         sx += (double)f; sxx += (double)(f * f);
     }
     template <int MODE, bool OPQ>
-    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t, uint32_t, bool, uint32_t bu, float thr)
+    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t, uint32_t, bool static_pad, uint32_t bu, float thr)
     {
         const float a = __uint_as_float(au), b = __uint_as_float(bu);   // a is 0.0 for excluded chip pixels and unused slots
-        if (MODE == M_FAST) {
+        if (MODE == M_FAST && static_pad && !OPQ) {
+            // a row task of a null-free chip: every slot is a pixel (one pixel per dword, no pad); the idle lanes of a short
+            // chip hold a = 0 and read the window's zero row, so they add nothing either way: no selects.  (Small chips only:
+            // on the 61/81-row chips the freer schedule costs registers -- ocw 40: 284 B of spills, 78.6 -> 91.5 ms.)
+            acc.sy += (double)b; acc.syy += (double)(b * b); acc.sxy += (double)(a * b);
+        } else if (MODE == M_FAST) {
             const bool on = au != 0u;                                    // unused tail slots only (the chip has no null here)
             const float bm = on ? b : 0.0f;
             acc.sy += (double)bm; acc.syy += (double)(bm * bm); acc.sxy += (double)(on ? a * b : 0.0f);
@@ -373,6 +378,7 @@ struct U8Point {
     int dx2, dy2, Dx2, Dy2, csx, csy, ncell;
     int sh;            // byte phase of window column 0 inside its aligned dword
     int PW;            // LDS window pitch, bytes
+    int zrow;          // an all-zero LDS row: the never-written last window row (T4), or one extra row behind a full-square search area
     float thr;         // smallest f32 whose f64 value is >= MIN_DN
 };
 
@@ -393,7 +399,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
 #pragma unroll
     for (int i = 0; i < C::RF; i++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + (l + C::LPC * i) * pt.PW);
-        if (C::SHORT && l >= C::CW) rp = reinterpret_cast<const uint32_t *>(W + (pt.Dy2 - 1) * pt.PW);   // idle lane: the zero row
+        if (C::SHORT && l >= C::CW) rp = reinterpret_cast<const uint32_t *>(W + pt.zrow * pt.PW);   // idle lane: the zero row
         uint32_t w[NLD];
 #pragma unroll
         for (int j = 0; j < NLD; j++) w[j] = rp[j];
@@ -466,10 +472,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         pt.dx2 = (lu < 0 ? -lu : lu) + OCW + 2;
         pt.dy2 = (lv < 0 ? -lv : lv) + OCW + 2;
     }
+    // full-square search area (get_offset_image hands find_ncc_peak a whole image chip, MIMC_module.c:347): every row and
+    // column is written, there is no empty last row / column (T4 applies to the DLC window of extract_sarea only)
+    const bool full_win = p.win_half > 0;
+    if (full_win) { pt.dx2 = p.win_half; pt.dy2 = p.win_half; }
     pt.Dx2 = 2 * pt.dx2 + 1; pt.Dy2 = 2 * pt.dy2 + 1;
     pt.csx = pt.Dx2 - 2 * OCW + 1; pt.csy = pt.Dy2 - 2 * OCW + 1;
     pt.ncell = pt.csx * pt.csy;
     pt.PW = p.lds_pw;
+    pt.zrow = 2 * pt.dy2 + (full_win ? 1 : 0);
     const int wu0 = u0 + p.off_u - pt.dx2 + PAD;     // plane column of window column 0
     const int wv0 = v0 + p.off_v - pt.dy2 + PAD;     // plane row of window row 0
     pt.sh = wu0 & (P::G - 1);                        // pixel phase of window column 0 inside its aligned dword
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     int bad_win = 0, exc_win = 0;                            // "x < MIN_DN" count (:631) / pixels the NCC loop skips (:723)
     int nbx0 = 1 << 20, nbx1 = -1, nby0 = 1 << 20, nby1 = -1;   // bounding box of the skipped pixels (window coords, dword-granular in x)
     {
-        const int wcols = 2 * pt.dx2, wrows = 2 * pt.dy2;                 // written area (:869-886)
+        const int wcols = 2 * pt.dx2 + (full_win ? 1 : 0), wrows = 2 * pt.dy2 + (full_win ? 1 : 0);   // written area (:869-886)
         const int nd = (pt.sh + wcols + P::G - 1) >> P::LOG2G;            // aligned dwords per row
         // every thread keeps ONE dword column c and walks down the rows r0, r0 + rstep, ...: column masks, addresses and the
         // LDS offset are loop invariants / plain increments (one division per thread instead of one per dword)
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     if (p.debug_stop == 1) return;
     MIMC3_STAMP(0)
     const bool win_clean = (exc_win == 0);                   // nothing the NCC loop would skip inside the written area
-    bad_win += pt.Dx2 + pt.Dy2 - 1;                          // + the never-written last row and column
+    if (!full_win) bad_win += pt.Dx2 + pt.Dy2 - 1;           // + the never-written last row and column
 
     // ---- chip -> registers (a4): every lane group holds the whole chip --------------------------
     constexpr int RFA = C::RF > 0 ? C::RF : 1, TTA = C::TT > 0 ? C::TT : 1;
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // a cell's 33x33 (CW x CW) box of the window is null-free iff it avoids the null bounding box and
     // the zero last row/column (T4)
     auto box_clean = [&](int cx, int cy) __attribute__((always_inline)) -> bool {
-        if (cx == pt.csx - 2 || cy == pt.csy - 2) return false;
+        if (!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)) return false;
         if (win_clean) return true;
         return (cx > nbx1) || (cx + CW - 1 < nbx0) || (cy > nby1) || (cy + CW - 1 < nby0);
     };
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 if constexpr (C::SPARSE) {
                     // one wave = one cell.  Unless the box touches the never-written last row/column (T4: a whole row of
                     // nulls) the cell is the FAST body plus corrections over the null lists.
-                    if (sparse_on && !(dirty_list && (cx == pt.csx - 2 || cy == pt.csy - 2))) {
+                    if (sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2))) {
                         AccT<Sum> a0{0, 0, 0, 0, 0, 0};
                         uint32_t cn = 0;
                         Sum csx = 0, csxx = 0, csy = 0, csyy = 0;
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 Store v[6] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
                 if constexpr (kAPark) {
                     // cells whose n, sx, sxx are the point's constants (minus the corrections that were added above)
-                    const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(cx == pt.csx - 2 || cy == pt.csy - 2));
+                    const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)));
                     if (!dense) { v[0] += (Store)NV; v[1] += P::bits(SX); v[3] += P::bits(SXX); }
                     if (C::SPARSE) v[0] = (Store)(uint32_t)v[0];          // n travels as a 32-bit count (corrections wrap modulo 2^32)
 #pragma unroll
@@ -1353,12 +1364,13 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
 {
     MatchU8Args tmp{};
     MatchU8Args &r = a ? *a : tmp;
-    const int Dx2 = 2 * (max_abs_u + C::OCW + 2) + 1, Dy2 = 2 * (max_abs_v + C::OCW + 2) + 1;
+    const bool full = r.win_half > 0;                       // full-square search area: no empty last row / column
+    const int Dx2 = full ? 2 * r.win_half + 1 : 2 * (max_abs_u + C::OCW + 2) + 1, Dy2 = full ? 2 * r.win_half + 1 : 2 * (max_abs_v + C::OCW + 2) + 1;
     const int cells = (Dx2 - 2 * C::OCW + 1) * (Dy2 - 2 * C::OCW + 1);
     // pitch (dwords): written dwords + one zero dword, and the right-most cell's sliding read-ahead
     const int csx = Dx2 - 2 * C::OCW + 1;
     constexpr int G = C::P::G, LG = C::P::LOG2G;
-    const int pw_a = ((G - 1 + (Dx2 - 1) + G - 1) >> LG) + 1, pw_b = ((G - 1 + csx - 2) >> LG) + C::GPR + 1;
+    const int pw_a = ((G - 1 + (Dx2 - 1) + (full ? 1 : 0) + G - 1) >> LG) + 1, pw_b = ((G - 1 + csx - 2) >> LG) + C::GPR + 1;
     r.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
     // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
@@ -1368,7 +1380,7 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     if (cap > cells) cap = cells;
     if (cap < 16) cap = 16;
     r.lds_list_cap = cap + 16;
-    size_t off = (size_t)r.lds_pw * Dy2;
+    size_t off = (size_t)r.lds_pw * (Dy2 + (full ? 1 : 0));     // + the zero row behind a full-square search area
     off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += 4 * (size_t)(csx - 2) * (Dy2 - 2 * C::OCW - 1);   // (csx-2) x (csy-2) cache words
     off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 2 * (size_t)r.lds_list_cap;
