@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmimc3_hip.so")
+LIB_PATH = os.environ.get("MIMC3_HIP_LIB") or os.path.join(_HERE, "csrc", "libmimc3_hip.so")   # (override: A/B builds in tools/)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

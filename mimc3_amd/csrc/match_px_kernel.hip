@@ -835,26 +835,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         for (int j = 0; j < 9; j++)
             if (old[j] == kUnknownBits) won |= 1u << j;
         if (!won) return;
-        // clean / dirty for the nine boxes from three column tests and three row tests (box_clean() nine times is 2.5x the
-        // VALU): a box is dirty iff its column AND its row meet the null bounding box, or it touches the T4 row / column
         uint32_t cl = 0;
-        {
-            const int xd0 = nbx0 - CW + 1, yd0 = nby0 - CW + 1;               // first dirty column / row
-            bool dxs[3], dys[3], txs[3], tys[3];
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const int cx = cx0 + d - 1, cy = cy0 + d - 1;
-                dxs[d] = !win_clean && (unsigned)(cx - xd0) <= (unsigned)(nbx1 - xd0);
-                dys[d] = !win_clean && (unsigned)(cy - yd0) <= (unsigned)(nby1 - yd0);
-                txs[d] = !full_win && cx == pt.csx - 2;
-                tys[d] = !full_win && cy == pt.csy - 2;
-            }
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const bool dirty = (dxs[j / 3] && dys[j % 3]) || txs[j / 3] || tys[j % 3];
-                if (!dirty) cl |= 1u << j;
-            }
-        }
+        for (int j = 0; j < 9; j++)
+            if (((won >> j) & 1u) && box_clean(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1))) cl |= 1u << j;
         const uint32_t wa = won & cl, wb = won & ~cl;
         const int na = __popc(wa), nb = __popc(wb);
         const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], na | (nb << 16));
@@ -1565,11 +1549,7 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxU8, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 16: {
-        static const int lpc8 = getenv("MIMC3_U8_16_LPC8") ? atoi(getenv("MIMC3_U8_16_LPC8")) : 0;   // experiment: 8 lanes per cell
-        if (lpc8) return launch_cfg<PxCfg<PxU8, 16, 8, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-        return launch_cfg<PxCfg<PxU8, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    }
+    case 16: return launch_cfg<PxCfg<PxU8, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     // big chips: 4 waves share one point's LDS image (one cell per wave and round)
     case 30: return launch_cfg<PxCfg<PxU8, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 32: return launch_cfg<PxCfg<PxU8, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
