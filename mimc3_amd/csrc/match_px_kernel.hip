@@ -344,7 +344,7 @@ struct PxF32 {
     }
 };
 
-template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2>
+template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2, bool CHL_ = false>
 struct PxCfg {
     typedef P_ P;
     static constexpr int MINW = MINW_;                       // occupancy target, waves per SIMD
@@ -370,6 +370,10 @@ struct PxCfg {
     // (17 VALU per dword).  One wave evaluates one cell, so 64 lanes share the list walk.
     static constexpr bool SPARSE = (LPC_ >= 64) && P::INTEGER;
     static constexpr int CPITCH = 4 * GPR;                   // LDS chip copy: bytes per row
+    // The evaluation reads the chip from its LDS copy instead of registers (SPARSE configs keep that copy anyway): the u16
+    // policy's 81-row chip is 52 dwords per lane next to a 42-dword window row in flight, which does not fit 128 or 168
+    // VGPRs; from LDS the kernel runs at twice the occupancy without spills (the kernel is VALU-bound, LDS has headroom).
+    static constexpr bool CHIP_LDS = CHL_ && SPARSE;
 };
 static constexpr int kLwCap = 1024;    // window-null list entries (x | y << 16); more -> the point falls back to GENERAL
 static constexpr int kLcCap = 512;     // chip-null list entries
@@ -389,13 +393,45 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
                                           const int (&toff)[C::TT > 0 ? C::TT : 1],
-                                          AccT<typename C::P::Sum> acc = AccT<typename C::P::Sum>{0, 0, 0, 0, 0, 0})
+                                          AccT<typename C::P::Sum> acc = AccT<typename C::P::Sum>{0, 0, 0, 0, 0, 0},
+                                          const unsigned char *CH = nullptr)
 {
     typedef typename C::P P;
     const int X = pt.sh + cx;                                       // pixel offset of the box inside the LDS row
     const uint32_t s = (uint32_t)((X & (P::G - 1)) * P::BPP);       // byte phase inside the first dword
     const unsigned char *base = W + cy * pt.PW + 4 * (X >> P::LOG2G);
     constexpr int NLD = C::GPR + (P::G > 1 ? 1 : 0);                // dwords a row task reads
+    if constexpr (C::CHIP_LDS) {
+        // chip AND window from LDS: the row is walked in chunks of eight dwords by a real loop (nothing to index in registers),
+        // which bounds the loads in flight -- a fully unrolled 41-dword row keeps 83 values live
+        constexpr int KC = 8;
+#pragma unroll
+        for (int i = 0; i < C::RF; i++) {
+            const bool idle = C::SHORT && l >= C::CW;
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(idle ? W + pt.zrow * pt.PW : base + (l + C::LPC * i) * pt.PW);
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(CH + (idle ? 0 : (l + C::LPC * i)) * C::CPITCH);
+#pragma unroll 1
+            for (int j0 = 0; j0 < C::GPR - 1; j0 += KC) {             // the full dwords of the row
+                uint32_t w[KC + 1], a[KC];
+#pragma unroll
+                for (int k = 0; k <= KC; k++) w[k] = rp[j0 + k];      // (reads a few dwords past a short last chunk: inside the pitch + next row)
+#pragma unroll
+                for (int k = 0; k < KC; k++) a[k] = (j0 + k < C::GPR - 1 && !idle) ? cp[j0 + k] : 0u;
+#pragma unroll
+                for (int k = 0; k < KC; k++) {
+                    const uint32_t bw = (P::G > 1) ? alignb(w[k + 1], w[k], s) : w[k];
+                    if (j0 + k < C::GPR - 1) P::template task<MODE, C::OPQ>(acc, a[k], 0x01010101u, 0xffffffffu, true, bw, pt.thr);
+                }
+            }
+            {                                                         // the last dword of the row (pad mask)
+                constexpr int j = C::GPR - 1;
+                const uint32_t w0 = rp[j], w1 = (P::G > 1) ? rp[j + 1] : 0u;
+                const uint32_t bw = (P::G > 1) ? alignb(w1, w0, s) : w0;
+                const uint32_t av = idle ? 0u : cp[j];
+                P::template task<MODE, C::OPQ>(acc, av, C::LAST01, C::LASTFF, true, bw, pt.thr);
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < C::RF; i++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + (l + C::LPC * i) * pt.PW);
@@ -411,11 +447,18 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
             P::template task<MODE, C::OPQ>(acc, A[i][j], p01, pff, true, bw, pt.thr);
         }
     }
+    }
 #pragma unroll
     for (int k = 0; k < C::TT; k++) {
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(base + toff[k]);
         const uint32_t bw = (P::G > 1) ? alignb(rp[P::G > 1 ? 1 : 0], rp[0], s) : rp[0];
-        P::template task<MODE, C::OPQ>(acc, AT[k], 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from AT[k] itself
+        uint32_t av = AT[k];
+        if constexpr (C::CHIP_LDS) {
+            // chip dword of tail task k: row RF*LPC + tt / GPR, dword tt % GPR (0 for the lanes past the last task)
+            const int tt = l + C::LPC * k;
+            av = tt < C::REM * C::GPR ? *reinterpret_cast<const volatile uint32_t *>(CH + (C::RF * C::LPC + tt / C::GPR) * C::CPITCH + 4 * (tt % C::GPR)) : 0u;
+        }
+        P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
     }
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
@@ -705,7 +748,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 A[i][j] = a;
                 P::chip_acc(SX, SXX, a);
                 if constexpr (C::SPARSE) {
-                    if (wave == 0 && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;
+                    if ((j % NW) == wave && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;   // every wave holds the whole chip: each writes a share of the copy
                 }
             }
         }
@@ -724,7 +767,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             toff[k] = rr * pt.PW + 4 * j;
             P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
-                if (wave == 0 && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
+                if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
             }
         }
         if (P::INTEGER && chip_susp) {                        // rare: the lane's chip dwords again, counted exactly (and listed)
@@ -950,7 +993,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         // 32 bits inside a 64-bit sum, so there the correction is subtracted after the body.)
                         constexpr bool kFold = sizeof(Sum) == 4;
                         if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
-                        acc = eval_round<C, M_FAST, false>(W, pt, cx, cy, l, A, AT, toff, a0);
+                        acc = eval_round<C, M_FAST, false>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
                         if (!kFold) { acc.sy -= csy; acc.syy -= csyy; }
                         acc.n = 0u - cn; acc.sx = (Sum)0 - csx; acc.sxx = (Sum)0 - csxx;      // + the point's constants, in the finish
                         done = true;
@@ -959,9 +1002,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                 }
                 if (!done) {
-                    if (mode == M_FAST) acc = eval_round<C, M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
-                    else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
-                    else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff);
+                    if (mode == M_FAST) acc = eval_round<C, M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                 }
                 Store *sp = sums + 6 * slot;
                 if constexpr (kAPark) {
@@ -1484,9 +1527,11 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU16, 16, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);   // (chip from LDS: 24.5 vs 21.6 ms)
     case 32: return launch_cfg<PxCfg<PxU16, 32, 64, 4, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);   // 216 VGPRs, no scratch: 44.7 ms vs 49.5 at 3 waves/SIMD with 192 B of spills
+    // 81-row chip at 2 px per dword = 52 chip dwords per lane: read from the LDS copy instead (3 waves/SIMD, 44 B of scratch
+    // outside the loops): 37.9 ms against 46.1 with the chip in 216 VGPRs at 2 waves/SIMD, measured side by side
+    case 40: return launch_cfg<PxCfg<PxU16, 40, 64, 4, 3, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }

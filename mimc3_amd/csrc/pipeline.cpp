@@ -154,19 +154,33 @@ HostPivots::~HostPivots() { if (uv) (void)hipHostFree(uv); }
 int vmap_host_pivots(const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W, int device,
                      HostPivots hp[4], std::string &err)
 {
-    (void)hipSetDevice(device);
-    for (int c = 0; c < 4 && ns > 0; c++) {
+    if (ns <= 0) return 0;
+    // the four chip sizes are independent: one host thread each (every one of them fans out again inside mimc3_get_uv_pivot)
+    int rcs[4] = {0, 0, 0, 0};
+    std::string errs[4];
+    auto one = [&](int c) {
+        (void)hipSetDevice(device);
         hp[c].off.resize((size_t)ns + 1);
         int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
         if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
-            err = "mimc3_vmap: hipHostMalloc for the pivots failed";
-            return MIMC3_ENODEV;
+            errs[c] = "mimc3_vmap: hipHostMalloc for the pivots failed";
+            rcs[c] = MIMC3_ENODEV;
+            return;
         }
         if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
                                          static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
         if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
-        if (rc) { err = mimc3_last_error(); return rc; }
+        if (rc) { errs[c] = mimc3_last_error(); rcs[c] = rc; }          // the message is thread-local: carry it over
+    };
+    if (ns >= 20000) {
+        std::thread th[3] = {std::thread(one, 1), std::thread(one, 2), std::thread(one, 3)};
+        one(0);
+        for (auto &t : th) t.join();
+    } else {
+        for (int c = 0; c < 4; c++) one(c);
     }
+    for (int c = 0; c < 4; c++)
+        if (rcs[c]) { err = errs[c]; return rcs[c]; }
     return 0;
 }
 
