@@ -306,6 +306,10 @@ int mimc3_ctx_device(mimc3_ctx *ctx);
  *      bytes; freed with the context.  The drivers above the ABI (mimc3_postprocess, mimc3_vmap) keep their working
  *      buffers here instead of allocating per call.  One stream at a time per context. */
 int mimc3_ctx_workspace(mimc3_ctx *ctx, int32_t slot, size_t bytes, void **d_ptr);
+/*      the same for PINNED host memory (slot 0..7): pinning pages costs milliseconds per tens of MB, so the drivers keep
+ *      their staging buffers (the pivot lists of the 32 passes) across calls.  Distinct slots may be asked for from
+ *      distinct host threads at the same time. */
+int mimc3_ctx_host_workspace(mimc3_ctx *ctx, int32_t slot, size_t bytes, void **h_ptr);
 
 /* ---- measurement helper: average device time (ms) of the last matcher launch sequence,
  *      taken with hipEvents on the launch stream (bench.py's roofline leg). -------------------- */

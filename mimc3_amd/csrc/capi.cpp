@@ -86,6 +86,8 @@ struct mimc3_ctx {
     // host -> device staging: two pinned chunks that a pageable source is pipelined through (a pinned source is DMA'd directly)
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    void *hslot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mimc3_ctx_host_workspace: pinned host scratch
+    size_t hslot_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DevBuf slot[16];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
@@ -220,6 +222,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     for (auto &b : c->fail_alt) b.release();
     c->raw_dn.release(); c->cellws.release();
     for (auto &b : c->slot) b.release();
+    for (auto &h : c->hslot) if (h) (void)hipHostFree(h);
     for (auto &pp : c->pin) if (pp) (void)hipHostFree(pp);
     for (auto &ev : c->ev_pin) if (ev) (void)hipEventDestroy(ev);
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
@@ -1150,6 +1153,20 @@ extern "C" int mimc3_ctx_workspace(mimc3_ctx *c, int32_t slot, size_t bytes, voi
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->slot[slot].reserve(bytes ? bytes : 1));
     *d_ptr = c->slot[slot].p;
+    return 0;
+}
+
+extern "C" int mimc3_ctx_host_workspace(mimc3_ctx *c, int32_t slot, size_t bytes, void **h_ptr)
+{
+    if (!c || !h_ptr || slot < 0 || slot >= 8) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_host_workspace: bad argument");
+    if (bytes > c->hslot_cap[slot]) {
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->hslot[slot]) { (void)hipHostFree(c->hslot[slot]); c->hslot[slot] = nullptr; c->hslot_cap[slot] = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipHostMalloc(&c->hslot[slot], want, hipHostMallocPortable));
+        c->hslot_cap[slot] = want;
+    }
+    *h_ptr = c->hslot[slot];
     return 0;
 }
 

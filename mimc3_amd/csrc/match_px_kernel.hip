@@ -596,20 +596,44 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         (void)gbase16; (void)gpitch16;
         if constexpr (P::SRC16) {
             // pass 1: local range of the window and of the chip; a point that does not fit 8 bits goes to the u16 kernel
+            // (both scans fetch eight values before they use any: the loops are chains of global loads otherwise)
             int mn = 1 << 20, mx = -1;
             if (col_on)
                 for (int c = c_first; c < nd; c += cstep) {
                     const uint32_t keep = col_keep(c);
-                    for (int r = r0; r < wrows; r += rstep) PxU8o::range4(gbase16[(size_t)r * gpitch16 + c], keep, mn, mx);
+                    for (int rb = r0; rb < wrows; rb += 8 * rstep) {
+                        uint2 t[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { const int r = rb + k * rstep; t[k] = gbase16[(size_t)(r < wrows ? r : rb) * gpitch16 + c]; }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if (rb + k * rstep < wrows) PxU8o::range4(t[k], keep, mn, mx);
+                    }
                 }
             int cmn = 1 << 20, cmx = -1;
             {
-                const unsigned short *c16 = reinterpret_cast<const unsigned short *>(chip_pl);
+                // the chip as aligned 4-pixel groups: row rr, group cc of the (GPR + 1) groups that cover its CW pixels
                 const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
-                for (int q = tid; q < C::NPX; q += NT) {
-                    const int rr = q / CW, cc = q - rr * CW;
-                    const int val = c16[(size_t)(cv0 + rr) * Wp + cu0 + cc];
-                    if (val) { cmn = min(cmn, val); cmx = max(cmx, val); }
+                const int cph = cu0 & 3;
+                const uint2 *cb = reinterpret_cast<const uint2 *>(chip_pl + ((size_t)cv0 * Wp + (cu0 - cph)) * 2);
+                constexpr int GR = GPR + 1, NG = CW * GR;
+                for (int q0 = tid; q0 < NG; q0 += 8 * NT) {
+                    uint2 t[8];
+                    int rr[8], cc[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int q = q0 + k * NT < NG ? q0 + k * NT : q0;
+                        rr[k] = q / GR; cc[k] = q - rr[k] * GR;
+                        t[k] = cb[(size_t)rr[k] * (Wp >> 2) + cc[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (q0 + k * NT >= NG) continue;
+                        // pixels of the group that belong to the chip: columns cph .. cph + CW - 1 of the row
+                        uint32_t keep = 0u;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) { const int col = 4 * cc[k] + b - cph; if (col >= 0 && col < CW) keep |= 0xffu << (8 * b); }
+                        PxU8o::range4(t[k], keep, cmn, cmx);
+                    }
                 }
             }
 #pragma unroll

@@ -365,7 +365,7 @@ extern "C" int mimc3_mgpu_vmap(mimc3_mgpu *mg, const double *xyuvav, int32_t N, 
         for (int32_t j = 0; j < n; j++) std::memcpy(&xs[6 * (size_t)j], xyuvav + 6 * (size_t)order[(size_t)(lo + j)], 48);
         mimc3::HostPivots hp[4];
         std::string err;
-        int rc = mimc3::vmap_host_pivots(xs.data(), n, dt, mpp, p, H, W, mg->dev[(size_t)r], hp, err);
+        int rc = mimc3::vmap_host_pivots(c, xs.data(), n, dt, mpp, p, H, W, hp, err);
         if (rc) return mimc3::fail(rc, err);
         return mimc3::vmap_run_passes(c, xs.data(), n, res->offset_cp, hp, p, static_cast<float *>(d_local), (size_t)per);
     }));

@@ -146,12 +146,12 @@ int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
     return 0;
 }
 
-HostPivots::~HostPivots() { if (uv) (void)hipHostFree(uv); }
+HostPivots::~HostPivots() {}     // the payload lives in the context's pinned host scratch (mimc3_ctx_host_workspace, slot = chip size index)
 
 // pivots of the four chip sizes (:264, :316) for the points xs[0..ns): host geometry (libm-exact, threaded) that depends
 // on nothing the CP stage produces; payload in pinned memory.  Safe to call from a worker thread (`device` = the device
 // whose context will upload them); the error text is returned because mimc3_last_error() is thread-local.
-int vmap_host_pivots(const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W, int device,
+int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W,
                      HostPivots hp[4], std::string &err)
 {
     if (ns <= 0) return 0;
@@ -159,14 +159,9 @@ int vmap_host_pivots(const double *xs, int32_t ns, float dt, float mpp, const mi
     int rcs[4] = {0, 0, 0, 0};
     std::string errs[4];
     auto one = [&](int c) {
-        (void)hipSetDevice(device);
         hp[c].off.resize((size_t)ns + 1);
         int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
-        if (!rc && hipHostMalloc(&hp[c].uv, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), hipHostMallocPortable) != hipSuccess) {
-            errs[c] = "mimc3_vmap: hipHostMalloc for the pivots failed";
-            rcs[c] = MIMC3_ENODEV;
-            return;
-        }
+        if (!rc) rc = mimc3_ctx_host_workspace(ctx, c, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), &hp[c].uv);   // pinned, kept across calls
         if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
                                          static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
         if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
@@ -289,8 +284,7 @@ extern "C" int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N
     int piv_rc = 0;
     std::string piv_err;
     const float mpp = res->mpp;
-    const int device = mimc3_ctx_device(ctx);
-    std::thread piv_worker([&]() { piv_rc = mimc3::vmap_host_pivots(xs, ns, dt, mpp, p, H, W, device, hp, piv_err); });
+    std::thread piv_worker([&]() { piv_rc = mimc3::vmap_host_pivots(ctx, xs, ns, dt, mpp, p, H, W, hp, piv_err); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{piv_worker};
     RC_TRY(mimc3::vmap_cp_offset(ctx, xyuvav, N, p, flag_cp, res));
     if (res->cp_status < 0) return 0;                       // the CLI touches vmap.tar and gives up (:248-252)
@@ -328,7 +322,7 @@ extern "C" int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_
     RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
     mimc3::HostPivots hp[4];
     std::string err;
-    int rc = mimc3::vmap_host_pivots(xs, n, dt, res->mpp, p, H, W, mimc3_ctx_device(ctx), hp, err);
+    int rc = mimc3::vmap_host_pivots(ctx, xs, n, dt, res->mpp, p, H, W, hp, err);
     if (rc) return mimc3::fail(rc, err);
     return mimc3::vmap_run_passes(ctx, xs, n, res->offset_cp, hp, p, d_dp, pass_stride > 0 ? (size_t)pass_stride : 0);
 }

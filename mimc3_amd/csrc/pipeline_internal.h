@@ -8,7 +8,7 @@
 
 namespace mimc3 {
 
-// host CSR pivots of one chip size for a set of points; payload in pinned memory
+// host CSR pivots of one chip size for a set of points; payload in the context's pinned host scratch
 struct HostPivots {
     std::vector<int64_t> off;
     void *uv = nullptr;
@@ -21,7 +21,7 @@ struct HostPivots {
 };
 
 int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res);
-int vmap_host_pivots(const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W, int device,
+int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W,
                      HostPivots hp[4], std::string &err);
 int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res);
 int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t off[2], HostPivots hp[4], const mimc3_vmap_params *p,
