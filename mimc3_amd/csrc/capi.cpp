@@ -2,6 +2,7 @@
 // host-buffer (drop-in) and device-buffer (resident) entry points of the matcher and QM paths.
 // No CPU fallback: every compute entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -92,7 +93,7 @@ struct mimc3_ctx {
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
     int32_t win_half = 0;               // internal (CP stage): > 0 = the next matcher calls use a full (2*win_half+1)^2 search area
-    mimc3_ctx *cp_child = nullptr;      // CP stage: a context of its own for the chip atlas (planes, kernel selection)
+    mimc3_ctx *cp_child[4] = {nullptr, nullptr, nullptr, nullptr};   // CP stage: one context per image variant for its chip atlas (planes, kernel selection)
     DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
     DevBuf raw_dn;                      // raw 8/16-bit DN as uploaded (mimc3_ctx_set_images_u8/_u16), widened on the device
 };
@@ -217,7 +218,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     c->qm_io.release(); c->qm_work.release();
     c->n1_io.release(); c->n1_work.release();
     c->filt0.release(); c->filt1.release(); c->conv_io.release(); c->cp_buf.release();
-    if (c->cp_child) { mimc3_ctx_destroy(c->cp_child); c->cp_child = nullptr; }
+    for (auto &ch : c->cp_child) if (ch) { mimc3_ctx_destroy(ch); ch = nullptr; }
     for (auto &b : c->ovf_alt) b.release();
     for (auto &b : c->fail_alt) b.release();
     c->raw_dn.release(); c->cellws.release();
@@ -376,13 +377,18 @@ extern "C" int mimc3_ctx_set_images_u16(mimc3_ctx *c, const uint16_t *i0, const 
     return prepare_u8(c);              // 16-bit files may still hold 8- or 12-bit DN: classified on the device as usual
 }
 
+static int set_images_dev_impl(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W, bool producer_unknown)
+{
+    c->d_i0 = c->raw_i0 = d_i0; c->d_i1 = c->raw_i1 = d_i1; c->H = H; c->W = W; c->filt_live = false;
+    HIP_TRY(hipSetDevice(c->device));
+    if (producer_unknown) HIP_TRY(hipDeviceSynchronize());   // make the pixels visible whatever stream produced them
+    return prepare_u8(c);
+}
+
 extern "C" int mimc3_ctx_set_images_dev(mimc3_ctx *c, const float *d_i0, const float *d_i1, int32_t H, int32_t W)
 {
     if (!c || !d_i0 || !d_i1 || H <= 0 || W <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_images_dev: bad argument");
-    c->d_i0 = c->raw_i0 = d_i0; c->d_i1 = c->raw_i1 = d_i1; c->H = H; c->W = W; c->filt_live = false;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());   // the caller's producer stream is unknown: make the pixels visible
-    return prepare_u8(c);
+    return set_images_dev_impl(c, d_i0, d_i1, H, W, true);
 }
 
 extern "C" int mimc3_ctx_enable_timing(mimc3_ctx *c, int32_t on)
@@ -894,9 +900,25 @@ struct Arena {
 };
 }  // namespace
 
+namespace {
+// MIMC3_CP_TIMING=1: wall time of the steps of the control-point stage on stderr
+struct CpClock {
+    bool on = getenv("MIMC3_CP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what, int a = -1, int b = -1)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mimc3 cp] %-22s %3d %3d %8.3f ms\n", what, a, b, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
 extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_t N, const mimc3_cp_params *p, int32_t offset[2],
                                       uint8_t *flag_cp, int32_t *status, int32_t *info, float *sduv_out)
 {
+    CpClock clk;
     if (!c || !xyuvav || !p || !offset || !flag_cp || !status || N <= 0)
         return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: bad argument");
     if (!c->raw_i0 || !c->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: images not set");
@@ -951,6 +973,7 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         rows.resize(w); uv.resize(2 * w);
     }
     const int32_t ncand = (int32_t)rows.size();
+    clk.mark("candidates");
     if (info) { info[0] = ncand; info[1] = num_cp; }
     if (ncand < p->num_cp_min) return 0;                                           // :119-123 (status -1)
     if (num_cp > ncand) num_cp = (int32_t)((float)ncand * 0.75);                   // :125-129
@@ -990,17 +1013,21 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     piv_off[nmax] = (int64_t)npiv * nmax;
 
     const size_t nm = (size_t)nmax;
-    const size_t need = al256(8 * nm) + al256(48 * nm) + al256(8 * npiv * nm) + al256(8 * (nm + 1)) + 2 * al256(4 * nm * cs * cs) +
-                        2 * al256(4 * nm * ts * ts) + 4 * al256(4 * nm) + al256(4 * 48 * nm) + al256(4 * 80 * nm) + al256(4 * nm) + 256;
+    // four image variants (raw, three pre-filters) x an atlas pair each, three pairs of stencil scratch
+    const size_t need = al256(8 * nm) + al256(48 * nm) + al256(8 * npiv * nm) + al256(8 * (nm + 1)) + 8 * al256(4 * nm * cs * cs) +
+                        6 * al256(4 * nm * ts * ts) + 12 * al256(4 * nm) + al256(4 * 48 * nm) + al256(4 * 80 * nm) + al256(4 * nm) + 256;
     HIP_TRY(c->cp_buf.reserve(need));
     Arena ar(c->cp_buf.p, c->cp_buf.cap);
     int32_t *d_uv = ar.take<int32_t>(2 * nm);
     double *d_xy = ar.take<double>(6 * nm);
     int32_t *d_piv = ar.take<int32_t>((size_t)2 * npiv * nm);
     int64_t *d_poff = ar.take<int64_t>(nm + 1);
-    float *d_a0 = ar.take<float>(nm * cs * cs), *d_a1 = ar.take<float>(nm * cs * cs);
-    float *d_t0 = ar.take<float>(nm * ts * ts), *d_t1 = ar.take<float>(nm * ts * ts);
-    float *d_imin0 = ar.take<float>(nm), *d_imin1 = ar.take<float>(nm), *d_mn0 = ar.take<float>(nm), *d_mn1 = ar.take<float>(nm);
+    float *d_a0[4], *d_a1[4], *d_t0[3], *d_t1[3], *d_imin0[3], *d_imin1[3], *d_mn0[3], *d_mn1[3];
+    for (int v = 0; v < 4; v++) { d_a0[v] = ar.take<float>(nm * cs * cs); d_a1[v] = ar.take<float>(nm * cs * cs); }
+    for (int k = 0; k < 3; k++) {
+        d_t0[k] = ar.take<float>(nm * ts * ts); d_t1[k] = ar.take<float>(nm * ts * ts);
+        d_imin0[k] = ar.take<float>(nm); d_imin1[k] = ar.take<float>(nm); d_mn0[k] = ar.take<float>(nm); d_mn1[k] = ar.take<float>(nm);
+    }
     float *d_dp = ar.take<float>(48 * nm);
     float *d_mvn = ar.take<float>(80 * nm);
     int32_t *d_ncl = ar.take<int32_t>(nm);
@@ -1008,12 +1035,15 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     HIP_TRY(hipMemcpyAsync(d_xy, xy_atlas.data(), 48 * nm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_piv, piv_all.data(), sizeof(int32_t) * piv_all.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_poff, piv_off.data(), 8 * (nm + 1), hipMemcpyHostToDevice, s));
+    for (auto &ch : c->cp_child) if (!ch) RC_TRY(mimc3_ctx_create(c->device, &ch));
 
+    clk.mark("setup + uploads");
     float sduv[2] = {0.0f, 0.0f};
     int32_t ncur = 0, segs = 0;
     bool ok = false;
     std::vector<int32_t> uv_seg;
-    std::vector<float> imin0(nmax), imin1(nmax), mn0(nmax), mn1(nmax), mvn((size_t)80 * nmax);
+    std::vector<float> imin0[3], imin1[3], mn0[3], mn1[3], mvn((size_t)80 * nmax);
+    for (int k = 0; k < 3; k++) { imin0[k].resize(nmax); imin1[k].resize(nmax); mn0[k].resize(nmax); mn1[k].resize(nmax); }
     std::vector<int32_t> ncl(nmax);
     for (int32_t sg = 0; sg < nseg; sg++) {
         const int32_t beg = seg[sg], n = seg[sg + 1] - seg[sg];
@@ -1022,70 +1052,84 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         uv_seg.resize(2 * (size_t)n);
         for (int32_t t = 0; t < n; t++) { uv_seg[2 * t] = uv[2 * order[beg + t]]; uv_seg[2 * t + 1] = uv[2 * order[beg + t] + 1]; }
         HIP_TRY(hipMemcpyAsync(d_uv, uv_seg.data(), 8 * (size_t)n, hipMemcpyHostToDevice, s));
-        for (int kk = -1; kk <= 2; kk++) {
-            if (kk < 0) {
-                HIP_TRY(mimc3::launch_cp_extract(c->raw_i0, H, W, d_uv, n, ocw_chip, d_a0, s));
-                HIP_TRY(mimc3::launch_cp_extract(c->raw_i1, H, W, d_uv, n, ocw_chip, d_a1, s));
-            } else {
-                const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
-                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t0, d_imin0, s));
-                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t1, d_imin1, s));
-                HIP_TRY(hipMemcpyAsync(imin0.data(), d_imin0, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipMemcpyAsync(imin1.data(), d_imin1, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                // the reference's output plane is reused from point to point (:259-262): its never-written border cells
-                // stay 0 (T4), its right-hand border columns accumulate the shifts (:2568-2582); both enter the minimum
-                const int ox = kw / 2, oy = kh / 2;
-                const bool has_zero = ox > 0 || oy > 0;
-                for (int im = 0; im < 2; im++) {
-                    const float *imn = im ? imin1.data() : imin0.data();
-                    float *mn = im ? mn1.data() : mn0.data();
-                    float b = 0.0f;
-                    for (int32_t t = 0; t < n; t++) {
-                        float m = 1e+37f;
-                        if (imn[t] < m) m = imn[t];
-                        if (has_zero && 0.0f < m) m = 0.0f;
-                        if (ox > 0 && b < m) m = b;
-                        mn[t] = m;
-                        if (ox > 0) b = (b != b) ? 0.0f : b - (m - 1.0f);
+        // ---- the chip atlases of the four image variants (tile t = candidate t): raw chips, then the three pre-filters.
+        //      The filters' minima go through the host once (the reference's plane-reuse rule below is a serial scan).
+        HIP_TRY(mimc3::launch_cp_extract(c->raw_i0, H, W, d_uv, n, ocw_chip, d_a0[0], s));
+        HIP_TRY(mimc3::launch_cp_extract(c->raw_i1, H, W, d_uv, n, ocw_chip, d_a1[0], s));
+        for (int kk = 0; kk < 3; kk++) {
+            const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
+            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t0[kk], d_imin0[kk], s));
+            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t1[kk], d_imin1[kk], s));
+            HIP_TRY(hipMemcpyAsync(imin0[kk].data(), d_imin0[kk], 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(imin1[kk].data(), d_imin1[kk], 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int kk = 0; kk < 3; kk++) {
+            // the reference's output plane is reused from point to point (:259-262): its never-written border cells
+            // stay 0 (T4), its right-hand border columns accumulate the shifts (:2568-2582); both enter the minimum
+            const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
+            const int ox = kw / 2, oy = kh / 2;
+            const bool has_zero = ox > 0 || oy > 0;
+            for (int im = 0; im < 2; im++) {
+                const float *imn = im ? imin1[kk].data() : imin0[kk].data();
+                float *mn = im ? mn1[kk].data() : mn0[kk].data();
+                float b = 0.0f;
+                for (int32_t t = 0; t < n; t++) {
+                    float m = 1e+37f;
+                    if (imn[t] < m) m = imn[t];
+                    if (has_zero && 0.0f < m) m = 0.0f;
+                    if (ox > 0 && b < m) m = b;
+                    mn[t] = m;
+                    if (ox > 0) b = (b != b) ? 0.0f : b - (m - 1.0f);
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(d_mn0[kk], mn0[kk].data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_mn1[kk], mn1[kk].data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+            HIP_TRY(mimc3::launch_cp_shift_copy(d_t0[kk], d_mn0[kk], n, ocw_chip, d_a0[kk + 1], s));
+            HIP_TRY(mimc3::launch_cp_shift_copy(d_t1[kk], d_mn1[kk], n, ocw_chip, d_a1[kk + 1], s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));                                          // the atlases are complete
+        clk.mark("atlases", sg);
+        // ---- every atlas is an image pair of its own, handed to a child context that classifies it (8-bit / scaled integers /
+        //      floats) and runs the same tiled kernels as the DLC passes: full-square search area (win_half), the 21x21 pivot
+        //      set as a replicated CSR
+        for (int v = 0; v < 4; v++) {
+            mimc3_ctx *ch = c->cp_child[v];
+            ch->path_mode = c->path_mode;
+            RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
+            ch->win_half = ocw_chip;
+        }
+        clk.mark("classify", sg);
+        // ---- the 16 matches (:330-384).  One match is a few hundred workgroups, latency-bound on its own: the four of a
+        //      variant (2 chip sizes x forward/swapped) go to four streams, each with its own overflow lists, and the four
+        //      variants follow each other on those streams without a host round trip in between
+        auto matches = [&]() -> int {
+            for (int v = 0; v < 4; v++) {
+                mimc3_ctx *ch = c->cp_child[v];
+                for (int c3 = 1; c3 < 3; c3++) {
+                    const int ocw = p->vec_ocw[c3];
+                    const int32_t slot = (c3 - 1) * 8 + v * 2;
+                    const int reach = ocw_chip - ocw - 2;
+                    for (int sw = 0; sw < 2; sw++) {
+                        const int lane_id = (c3 - 1) * 2 + sw;                     // 0..3
+                        hipStream_t ms = lane_id == 0 ? s : c->side[lane_id - 1];
+                        float *o = d_dp + (size_t)(slot + sw) * n * 3;
+                        ch->lane = lane_id;
+                        int rc = mimc3_match_ncc_dlc_dev(ch, d_xy, n, 0, 0, d_piv, d_poff, npiv, reach, reach, ocw, sw, o, ms);
+                        ch->lane = 0;
+                        if (rc) return rc;
+                        if (sw) HIP_TRY(mimc3::launch_negate_uv(o, n, ms));         // :376-377
                     }
                 }
-                HIP_TRY(hipMemcpyAsync(d_mn0, mn0.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
-                HIP_TRY(hipMemcpyAsync(d_mn1, mn1.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
-                HIP_TRY(mimc3::launch_cp_shift_copy(d_t0, d_mn0, n, ocw_chip, d_a0, s));
-                HIP_TRY(mimc3::launch_cp_shift_copy(d_t1, d_mn1, n, ocw_chip, d_a1, s));
             }
-            // the four matches of this image variant (2 chip sizes x forward/swapped): the chip atlas is an image pair of its
-            // own (tile t = candidate t), handed to a child context that classifies it (8-bit / scaled integers / floats) and
-            // runs the same tiled kernels as the DLC passes -- full-square search area (win_half), the 21x21 pivot set as a
-            // replicated CSR
-            HIP_TRY(hipStreamSynchronize(s));                                      // the atlas is complete
-            if (!c->cp_child) RC_TRY(mimc3_ctx_create(c->device, &c->cp_child));
-            mimc3_ctx *ch = c->cp_child;
-            ch->path_mode = c->path_mode;
-            RC_TRY(mimc3_ctx_set_images_dev(ch, d_a0, d_a1, n * cs, cs));
-            ch->win_half = ocw_chip;
-            // a match is a few hundred workgroups (latency-bound on its own): the four run side by side on four streams,
-            // each with its own overflow lists
-            for (int c3 = 1; c3 < 3; c3++) {                                       // :330-384
-                const int ocw = p->vec_ocw[c3];
-                const int32_t slot = (c3 - 1) * 8 + (kk + 1) * 2;
-                const int reach = ocw_chip - ocw - 2;
-                for (int sw = 0; sw < 2; sw++) {
-                    const int lane_id = (c3 - 1) * 2 + sw;                         // 0..3
-                    hipStream_t ms = lane_id == 0 ? ch->stream : c->side[lane_id - 1];
-                    float *o = d_dp + (size_t)(slot + sw) * n * 3;
-                    ch->lane = lane_id;
-                    int rc = mimc3_match_ncc_dlc_dev(ch, d_xy, n, 0, 0, d_piv, d_poff, npiv, reach, reach, ocw, sw, o, ms);
-                    ch->lane = 0;
-                    if (rc) { ch->win_half = 0; return rc; }
-                    if (sw) HIP_TRY(mimc3::launch_negate_uv(o, n, ms));             // :376-377
-                }
-            }
-            ch->win_half = 0;
-            HIP_TRY(hipStreamSynchronize(ch->stream));                             // the next variant overwrites the atlas
-            for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
-        }
+            return 0;
+        };
+        const int mrc = matches();
+        for (auto &ch : c->cp_child) ch->win_half = 0;
+        for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (mrc) return mrc;
+        clk.mark("matches", sg);
         // ---- clusters of the 16 matches; those holding >= 60 % vote with their mean (:392-413)
         mimc3::ClusterArgs ca{};
         ca.dp = d_dp; ca.ndp = 16; ca.N = n; ca.Kmax = 16; ca.mvn = d_mvn; ca.nclus = d_ncl; ca.kmax_seen = d_kmax;
@@ -1101,6 +1145,7 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                     flag_cp[rows[order[beg + t]]] = 1;
                     ncur++;
                 }
+        clk.mark("clusters + votes", sg, n);
         if (num_cp <= ncur) { ok = true; break; }                                  // :424-430
     }
     if (info) { info[2] = segs; info[3] = ncur; }

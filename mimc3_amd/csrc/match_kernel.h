@@ -56,6 +56,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     // LDS carve, filled by the launcher
     int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists
+    int32_t lds_off_traj;                           // many-pivot configs: recorded climbs of the pivots beyond the first 64
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off

@@ -344,7 +344,7 @@ struct PxF32 {
     }
 };
 
-template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2, bool CHL_ = false>
+template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2, bool CHL_ = false, bool MANY_ = false>
 struct PxCfg {
     typedef P_ P;
     static constexpr int MINW = MINW_;                       // occupancy target, waves per SIMD
@@ -374,6 +374,10 @@ struct PxCfg {
     // policy's 81-row chip is 52 dwords per lane next to a 42-dword window row in flight, which does not fit 128 or 168
     // VGPRs; from LDS the kernel runs at twice the occupancy without spills (the kernel is VALU-bound, LDS has headroom).
     static constexpr bool CHIP_LDS = CHL_ && SPARSE;
+    // Pivot sets of more than 64 (the 21x21 set of the control-point stage): the pivots beyond the first 64 have no lane of
+    // their own; their speculative climbs are recorded in LDS so that the exact replay stays on the fast form.  A separate
+    // instantiation: the plain configurations keep their register allocation.
+    static constexpr bool MANYP = MANY_;
 };
 static constexpr int kLwCap = 1024;    // window-null list entries (x | y << 16); more -> the point falls back to GENERAL
 static constexpr int kLcCap = 512;     // chip-null list entries
@@ -1089,6 +1093,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     int nsc = 0;                                     // scans recorded so far
     bool replay_generic = false;
     bool cut = false;                                // this lane's speculation was stopped before its climb ended
+    // many-pivot configurations: pivots lane+64, lane+128, ... -- bit j of xdone: pivot lane + 64 (j + 1) is recorded
+    uint32_t xdone = 0u;
+    bool xpending = false;
+    unsigned long long *trajL = reinterpret_cast<unsigned long long *>(smem + (C::MANYP ? p.lds_off_traj : 0));   // [npiv] recorded climbs
+    unsigned char *tinfo = reinterpret_cast<unsigned char *>(trajL + npiv);      // [npiv] scans recorded | still climbing << 7
+    unsigned char *Tl = tinfo + npiv;                                            // [npiv] scans really performed (exact replay)
+    (void)xdone; (void)xpending; (void)trajL; (void)tinfo; (void)Tl;
     // wave-uniform state of the reference's loops (:691-753)
     int k = 0, pu = 0, pvv = 0, du = 0, dv = 0, newncc = 0;
     bool fresh = true;
@@ -1147,14 +1158,52 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     if ((ldu | ldv) != 0 && inside(su + la * ldu, sv + la * ldv))
                         request9(su + la * ldu - OCW, sv + la * ldv - OCW);
             }
+            // Pivots beyond the first 64 (the 21x21 set of the control-point stage) have no lane of their own: each lane walks
+            // pivots lane+64, lane+128, ... from their starts over the cached values.  A walk that runs into cells it cannot
+            // read queues them and is repeated in the next stage; one that gets through is recorded in LDS (trajectory, scan
+            // count, still-climbing flag) for the exact replay and never walked again.
+            if constexpr (C::MANYP) {
+                xpending = false;
+                int j = 0;
+                for (int k2 = lane + 64; k2 < npiv; k2 += 64, j++) {
+                    if (j < 32 && ((xdone >> j) & 1u)) continue;
+                    int eu = pivs[2 * k2] + pt.dx2, ev = pivs[2 * k2 + 1] + pt.dy2;
+                    bool go = inside(eu, ev), stalled = false;
+                    float em = -2.0f;
+                    unsigned long long tr = 0ull;
+                    int n = 0;
+                    while (go && n < kSpecRounds) {
+                        int mv = -1;
+                        float sm = em;
+                        bool known = true;
+#pragma unroll
+                        for (int jj = 0; jj < 9; jj++) {
+                            const float v = lookup(eu + (jj / 3 - 1) - OCW, ev + (jj % 3 - 1) - OCW);
+                            known = known && !(v >= 2.5f);
+                            if (v > sm) { sm = v; mv = jj; }
+                        }
+                        if (!known) { request9(eu - OCW, ev - OCW); stalled = true; break; }
+                        em = sm;
+                        const bool moved = (mv >= 0 && mv != 4);
+                        if (moved) { eu += mv / 3 - 1; ev += mv % 3 - 1; }
+                        tr |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * n);
+                        n++;
+                        go = moved && inside(eu, ev);
+                    }
+                    if (stalled) { xpending = true; continue; }
+                    trajL[k2] = tr;
+                    tinfo[k2] = (unsigned char)(n | (go ? 0x80 : 0));
+                    if (j < 32) xdone |= 1u << j;
+                }
+            }
             stage++;
             MIMC3_STAMP(4)
-            const bool more = __any(alive && !cut && nsc < kSpecRounds);
+            const bool more = __any((alive && !cut && nsc < kSpecRounds) || xpending) && stage < kSpecRounds;
             if (more && qcnt[0] != 0) return 0;                      // evaluate the queued cells, then scan on
             // A lane that is still alive here had its speculation CUT (kSpecRounds scans, or the edge of the cache band).  Real
             // climbs are usually much shorter than speculative ones (the visited state ends them), so the exact replay runs
             // on the recorded prefixes first; only if a cut pivot really consumes its whole prefix the generic loops take over.
-            replay_generic = (npiv > 64);
+            replay_generic = C::MANYP ? (__any(xpending) != 0) : (npiv > 64);   // (plain configurations record the first 64 pivots only)
             stage = kSpecRounds;
             if (qcnt[0] != 0) return 0;                             // evaluate what was queued first
         }
@@ -1171,10 +1220,26 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // round trip in this sequential chain).  Otherwise the LDS bit array is used.
             uint32_t vlo = 0, vhi = 0;
             const int c1 = lane / 3 - 1, c2 = lane % 3 - 1;
+            unsigned long long ntr = 0ull;           // many-pivot configurations: the record of pivot kk + 1 (>= 64), read one pivot ahead
+            int nqu = 0, nqv = 0, ninfo = 0;
+            bool xcut = false;
             for (int kk = 0; kk < npiv; kk++) {
-                const unsigned long long tr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(traj >> 32), kk) << 32) |
-                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)traj, kk);
-                int qu = __builtin_amdgcn_readlane(start_u, kk), qv = __builtin_amdgcn_readlane(start_v, kk);
+                unsigned long long tr;
+                int qu, qv, info = 0;
+                if (!C::MANYP || kk < 64) {
+                    tr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(traj >> 32), kk) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)traj, kk);
+                    qu = __builtin_amdgcn_readlane(start_u, kk); qv = __builtin_amdgcn_readlane(start_v, kk);
+                } else {
+                    tr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ntr >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ntr);
+                    qu = __builtin_amdgcn_readfirstlane(nqu); qv = __builtin_amdgcn_readfirstlane(nqv);
+                    info = __builtin_amdgcn_readfirstlane(ninfo);
+                }
+                if (C::MANYP && kk + 1 >= 64 && kk + 1 < npiv) {
+                    ntr = trajL[kk + 1]; ninfo = tinfo[kk + 1];
+                    nqu = pivs[2 * (kk + 1)] + pt.dx2; nqv = pivs[2 * (kk + 1) + 1] + pt.dy2;
+                }
                 bool cont = true;
                 int Tk = 0;
                 for (int t = 0; t < kSpecRounds; t++) {
@@ -1202,9 +1267,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     if (moved) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; qu += q3 - 1; qv += (mv - 3 * q3) - 1; }
                     cont = moved && (unv != 0);
                 }
-                if (lane == kk) T = Tk;
+                if (!C::MANYP || kk < 64) {
+                    if (lane == kk) T = Tk;
+                } else {
+                    if (lane == 0) Tl[kk] = (unsigned char)Tk;
+                    xcut = xcut || ((info & 0x80) != 0 && Tk == (info & 0x7f));
+                }
             }
-            if (__any(alive && T == nsc)) {          // a cut pivot really went through its whole recorded prefix: the generic loops decide
+            if (__any(alive && T == nsc) || xcut) {          // a cut pivot really went through its whole recorded prefix: the generic loops decide
                 replay_generic = true;
                 if (!regmask)                        // the large-grid form marked its scans in LDS: start over from a clean visited set
                     for (int i = lane; i < ((pt.csy * vpitch) >> 5); i += 64) vis[i] = 0u;
@@ -1222,10 +1292,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const int code = (int)((traj >> (4 * t)) & 15ull);
                 if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
             }
-            const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
+            uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
             const float fmax = upd ? lookup(fu - OCW, fv - OCW) : -2.0f;
             float bv = (lane < npiv) ? fmax : -__builtin_inff();
             int bi = lane;
+            if constexpr (C::MANYP) {            // the lane's other pivots, in pivot order: a later one must be strictly better (:747)
+                for (int k2 = lane + 64; k2 < npiv; k2 += 64) {
+                    const unsigned long long tr2 = trajL[k2];
+                    const int T2 = Tl[k2];
+                    int gu = pivs[2 * k2] + pt.dx2, gv = pivs[2 * k2 + 1] + pt.dy2;
+                    bool upd2 = false;
+                    for (int t = 0; t < T2; t++) {
+                        const int code = (int)((tr2 >> (4 * t)) & 15ull);
+                        if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; gu += q3 - 1; gv += (mv - 3 * q3) - 1; upd2 = true; }
+                    }
+                    const float g = upd2 ? lookup(gu - OCW, gv - OCW) : -2.0f;
+                    if (g > bv) { bv = g; bi = k2; fpos = ((uint32_t)gv << 16) | (uint32_t)gu; }
+                }
+            }
             argmax_row16(bv, bi);
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
@@ -1236,7 +1320,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             bv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
             bi = __builtin_amdgcn_readfirstlane(bi);
             if (bv > -2.0f) {                            // strict >, first pivot attaining the maximum wins
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)fpos, bi);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)fpos, bi & 63);   // pivot bi lives on lane bi mod 64
                 peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
             }
             return 1;
@@ -1453,6 +1537,9 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 2 * (size_t)r.lds_list_cap;
     off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 128;
     off = (off + 15) & ~(size_t)15; r.lds_off_piv = (int)off; off += 8 * (size_t)max_npiv;
+    if (C::MANYP) {     // per pivot: 8 B trajectory + 1 B (scans recorded | still climbing << 7) + 1 B scans really performed
+        off = (off + 15) & ~(size_t)15; r.lds_off_traj = (int)off; off += 10 * (size_t)max_npiv;
+    }
     if (C::SPARSE) {
         off = (off + 15) & ~(size_t)15; r.lds_off_chip = (int)off; off += (size_t)C::CPITCH * C::CW;
         off = (off + 15) & ~(size_t)15; r.lds_off_lw = (int)off; off += 4 * (size_t)kLwCap;
@@ -1547,6 +1634,10 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
+    if (max_npiv > 64) {           // rectangular pivot sets (control-point stage): the many-pivot forms of its two chip sizes
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        if (a.ocw == 30) return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    }
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxU16, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
@@ -1563,6 +1654,10 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
 hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
+    if (max_npiv > 64) {
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        if (a.ocw == 30) return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    }
     switch (a.ocw) {       // the u8 configurations, fed from u16 planes through per-point offsets
     case 7: return launch_cfg<PxCfg<PxU8o, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
@@ -1615,6 +1710,10 @@ bool match_u8_supported(int ocw, int max_reach_u, int max_reach_v)
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
+    if (max_npiv > 64) {
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        if (a.ocw == 30) return launch_cfg<PxCfg<PxU8, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    }
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxU8, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
