@@ -17,6 +17,10 @@
  *   - "_dev" functions take DEVICE pointers and enqueue on the given hipStream_t (passed as
  *     void*; NULL = the default stream) without synchronising; the others take HOST pointers,
  *     copy, run, and synchronise (drop-in semantics).
+ *   - a context owns scratch that its calls share (overflow lists, planes, staging buffers): keep ONE stream in flight
+ *     per context -- issue the "_dev" calls of a context on one stream, and drain it before a call that rebuilds the
+ *     planes (set_images*, filter_images).  Concurrency comes from several contexts (one per device, or several per
+ *     device: the control-point stage does exactly that internally).
  *   - there is NO CPU fallback anywhere in this library.
  */
 #ifndef MIMC3_HIP_H

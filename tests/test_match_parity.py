@@ -337,6 +337,36 @@ def test_long_corridor_big_chip_falls_back_when_lds_is_short(api, oracle, reach,
     assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
 
 
+@pytest.mark.parametrize("mode", ["auto", "u16"])
+@pytest.mark.parametrize("ocw,angle", [(15, 10.0), (30, 10.0), (30, 80.0)])
+def test_corridor_of_more_than_64_pivots(api, oracle, ocw, angle, mode):
+    """~100 pivots per point at the two chip sizes that have a many-pivot kernel form (the control-point stage's): the pivots
+    beyond the first 64 are climbed by lanes that already own a pivot and recorded in LDS; the exact replay reads them from
+    there (visited bits in LDS: the compact grid is wider than 64 cells).  Raw pair (u8 / u16 kernels), its d/dx (u8 through
+    per-point offsets), forward and swapped."""
+    c = synth.make_small(seed=900 + ocw, shift=(5, -5), angle_deg=angle, ocw=ocw, speed=17000.0,
+                         h=(2 * (40 + ocw) + 140) if angle < 45 else 2 * (100 + ocw + 2) + 140,
+                         w=(2 * (100 + ocw + 2) + 140) if angle < 45 else 2 * (40 + ocw) + 140, dimx=3, dimy=3,
+                         margin=100 + ocw + 20, noise_dn=2, null_frac=0.02)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
+    assert np.diff(off).min() > 64
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        ctx.set_path(mode)
+        got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+        assert ctx.last_path() == {"auto": "u8_exact", "u16": "u16_scaled"}[mode]
+        sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
+        assert_bits_equal(got, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw))
+        assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
+        if mode == "auto":
+            ctx.filter_images(api.CLI_KERNELS[0])
+            f0, f1 = ctx.get_images(H, W)
+            gf = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
+            assert ctx.last_path() in ("u8_exact", "u8_offset", "u16_scaled")      # (small gradients can still be 8-bit)
+            assert_bits_equal(gf, oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, c.ocw), "d/dx")
+
+
 def test_long_corridor_16bit_and_float_pairs(api, oracle):
     """the same corridor on imagery that has no integer kernel (16-bit DN, floats): previously 'match kernel launch:
     invalid argument', now the general kernel"""
