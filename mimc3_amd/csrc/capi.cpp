@@ -90,6 +90,7 @@ struct mimc3_ctx {
     void *hslot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mimc3_ctx_host_workspace: pinned host scratch
     size_t hslot_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DevBuf slot[16];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
+    bool no_u8o = false;                // internal (CP stage): never try the per-point-offset u8 form on this context's pairs
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
     int32_t win_half = 0;               // internal (CP stage): > 0 = the next matcher calls use a full (2*win_half+1)^2 search area
@@ -289,7 +290,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
             // 9-bit integers (gradients of 8-bit images): does the LOCAL range fit 8 bits almost everywhere?  Then the
             // u8 kernels can run them through per-point offsets (PxU8o); the few points that do not fit go to PxU16.
             c->u8o_ok = false;
-            if (s0 == 0 && s1 == 0 && !getenv("MIMC3_NO_U8O")) {
+            if (s0 == 0 && s1 == 0 && !c->no_u8o && !getenv("MIMC3_NO_U8O")) {
                 int t[4] = {0, 0, 0, 0};
                 HIP_TRY(c->flag.reserve(4 * sizeof(int)));
                 HIP_TRY(hipMemsetAsync(c->flag.p, 0, 4 * sizeof(int), c->stream));
@@ -997,20 +998,9 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         nmax = std::max(nmax, seg[k] - seg[k - 1]);
     }
 
-    // ---- common rectangular pivot set (:150-162), replicated per point for the CSR interface
+    // ---- common rectangular pivot set (:150-162), replicated per point for the CSR interface (filled on the device)
     const int32_t npiv = (int32_t)((p->aw_cre * 2 + 1) * (p->aw_cre * 2 + 1));
-    std::vector<int32_t> piv;
-    for (int a = -awc; a <= awc; a++) for (int b = -awc; b <= awc; b++) { piv.push_back(a); piv.push_back(b); }
-    if ((int32_t)piv.size() != 2 * npiv) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: AW_CRE must be integral");
-    std::vector<int32_t> piv_all((size_t)2 * npiv * nmax);
-    std::vector<int64_t> piv_off((size_t)nmax + 1);
-    std::vector<double> xy_atlas((size_t)6 * nmax, 0.0);
-    for (int32_t t = 0; t < nmax; t++) {
-        std::memcpy(&piv_all[(size_t)2 * npiv * t], piv.data(), sizeof(int32_t) * 2 * npiv);
-        piv_off[t] = (int64_t)npiv * t;
-        xy_atlas[6 * (size_t)t + 2] = ocw_chip; xy_atlas[6 * (size_t)t + 3] = (double)t * cs + ocw_chip;
-    }
-    piv_off[nmax] = (int64_t)npiv * nmax;
+    if (npiv != (2 * awc + 1) * (2 * awc + 1)) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: AW_CRE must be integral");
 
     const size_t nm = (size_t)nmax;
     // four image variants (raw, three pre-filters) x an atlas pair each, three pairs of stencil scratch
@@ -1032,9 +1022,7 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     float *d_mvn = ar.take<float>(80 * nm);
     int32_t *d_ncl = ar.take<int32_t>(nm);
     int32_t *d_kmax = ar.take<int32_t>(1);
-    HIP_TRY(hipMemcpyAsync(d_xy, xy_atlas.data(), 48 * nm, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_piv, piv_all.data(), sizeof(int32_t) * piv_all.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_poff, piv_off.data(), 8 * (nm + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(mimc3::launch_cp_fill_problem(d_xy, d_piv, d_poff, nmax, awc, ocw_chip, cs, s));
     for (auto &ch : c->cp_child) if (!ch) RC_TRY(mimc3_ctx_create(c->device, &ch));
 
     clk.mark("setup + uploads");
@@ -1093,19 +1081,18 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         // ---- every atlas is an image pair of its own, handed to a child context that classifies it (8-bit / scaled integers /
         //      floats) and runs the same tiled kernels as the DLC passes: full-square search area (win_half), the 21x21 pivot
         //      set as a replicated CSR
-        for (int v = 0; v < 4; v++) {
-            mimc3_ctx *ch = c->cp_child[v];
-            ch->path_mode = c->path_mode;
-            RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
-            ch->win_half = ocw_chip;
-        }
-        clk.mark("classify", sg);
-        // ---- the 16 matches (:330-384).  One match is a few hundred workgroups, latency-bound on its own: the four of a
-        //      variant (2 chip sizes x forward/swapped) go to four streams, each with its own overflow lists, and the four
-        //      variants follow each other on those streams without a host round trip in between
+        //      The 16 matches (:330-384): one match is a few hundred workgroups, latency-bound on its own -- the four of a
+        //      variant (2 chip sizes x forward/swapped) go to four streams, each with its own overflow lists, and the variants
+        //      follow each other on those streams without a host round trip; variant v+1 is classified while v's matches run
         auto matches = [&]() -> int {
             for (int v = 0; v < 4; v++) {
                 mimc3_ctx *ch = c->cp_child[v];
+                ch->path_mode = c->path_mode;
+                // gradients go straight to the u16 kernel: over a whole 85x85 search area their range rarely fits the 8 bits
+                // of the per-point-offset form, and a second launch for the points that do not costs a full kernel latency
+                ch->no_u8o = true;
+                RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
+                ch->win_half = ocw_chip;
                 for (int c3 = 1; c3 < 3; c3++) {
                     const int ocw = p->vec_ocw[c3];
                     const int32_t slot = (c3 - 1) * 8 + v * 2;
@@ -1129,7 +1116,7 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamSynchronize(s));
         if (mrc) return mrc;
-        clk.mark("matches", sg);
+        clk.mark("classify + matches", sg);
         // ---- clusters of the 16 matches; those holding >= 60 % vote with their mean (:392-413)
         mimc3::ClusterArgs ca{};
         ca.dp = d_dp; ca.ndp = 16; ca.N = n; ca.Kmax = 16; ca.mvn = d_mvn; ca.nclus = d_ncl; ca.kmax_seen = d_kmax;

@@ -23,6 +23,9 @@ hipError_t launch_negate_uv(float *out, int32_t n, hipStream_t stream);
 // out[i] = -in[i]: the pivots of a swapped pass (MIMC_main.c:272-279)
 hipError_t launch_negate_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t stream);
 
+// xy [n][6], piv [n][(2*awc+1)^2][2], poff [n+1] of the control-point stage's matcher problem (tile t of the chip atlas)
+hipError_t launch_cp_fill_problem(double *xy, int32_t *piv, int64_t *poff, int32_t n, int32_t awc, int32_t half, int32_t cs, hipStream_t stream);
+
 // multi-GPU re-assembly of all-gathered blocks: g [world][npass][per][3], perm [world*per] (grid index, -1 = padding)
 // -> out [npass][N][3]
 hipError_t launch_scatter_blocks(const float *g, const int32_t *perm, int32_t world, int32_t per, int32_t npass, int32_t N, float *out,

@@ -8,6 +8,7 @@
 // the per-chip interior minimum are computed here for all chips at once; the tiny sequential recurrence over the
 // chips (border state -> minimum -> shift) runs on the host between the two launches (capi.cpp).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "cp_kernel.h"
 
@@ -137,6 +138,31 @@ hipError_t launch_scatter_blocks(const float *g, const int32_t *perm, int32_t wo
     const int64_t n = (int64_t)world * per;
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, perm, world, per, npass, N, out);
+    return hipGetLastError();
+}
+
+// the matcher problem of the control-point stage, identical for every candidate: tile t of the chip atlas is a grid point at
+// (half, t*cs + half) with the (2*awc+1)^2 pivot set (MIMC_module.c:150-162) -- xy [n][6], piv [n][npiv][2], poff [n+1]
+__global__ __launch_bounds__(256) void cp_fill_problem(double *__restrict__ xy, int32_t *__restrict__ piv, int64_t *__restrict__ poff,
+                                                         int n, int awc, int half, int cs)
+{
+    const int side = 2 * awc + 1, npiv = side * side;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)n * npiv) {
+        const int k = (int)(i % npiv);
+        piv[2 * i] = k / side - awc; piv[2 * i + 1] = k % side - awc;
+    }
+    if (i <= n) poff[i] = (int64_t)npiv * i;
+    if (i < n) {
+        double *r = xy + 6 * i;
+        r[0] = 0.0; r[1] = 0.0; r[2] = (double)half; r[3] = (double)i * cs + half; r[4] = 0.0; r[5] = 0.0;
+    }
+}
+
+hipError_t launch_cp_fill_problem(double *xy, int32_t *piv, int64_t *poff, int32_t n, int32_t awc, int32_t half, int32_t cs, hipStream_t stream)
+{
+    const int64_t npiv = (int64_t)(2 * awc + 1) * (2 * awc + 1), work = std::max<int64_t>(n * npiv, (int64_t)n + 1);
+    hipLaunchKernelGGL(cp_fill_problem, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, xy, piv, poff, n, awc, half, cs);
     return hipGetLastError();
 }
 

@@ -1634,8 +1634,11 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
-    if (max_npiv > 64) {           // rectangular pivot sets (control-point stage): the many-pivot forms of its two chip sizes
-        if (a.ocw == 15) return launch_cfg<PxCfg<PxU16, 15, 32, 1, 3, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    // Rectangular pivot sets (control-point stage): the many-pivot forms of its two chip sizes.  Those launches are a few
+    // hundred points of several hundred cells each -- latency-bound, so the small chip also gets four waves per point and
+    // 32 lanes per cell (8 cells per round instead of 4 on one wave).
+    if (max_npiv > 64) {
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU16, 15, 32, 4, 3, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         if (a.ocw == 30) return launch_cfg<PxCfg<PxU16, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     }
     switch (a.ocw) {
@@ -1655,7 +1658,7 @@ hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
     if (max_npiv > 64) {
-        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8o, 15, 32, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         if (a.ocw == 30) return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     }
     switch (a.ocw) {       // the u8 configurations, fed from u16 planes through per-point offsets
@@ -1711,7 +1714,7 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
     if (max_npiv > 64) {
-        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        if (a.ocw == 15) return launch_cfg<PxCfg<PxU8, 15, 32, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         if (a.ocw == 30) return launch_cfg<PxCfg<PxU8, 30, 64, 4, 4, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     }
     switch (a.ocw) {
