@@ -411,6 +411,21 @@ extern "C" int mimc3_ctx_last_kernel_ms(mimc3_ctx *c, float *ms)
 // ---------------------------------------------------------------------------------------------
 // matcher
 // ---------------------------------------------------------------------------------------------
+// zero-bordered f32 copies of the pair for the register-tiled f32 kernel, once per image pair (enqueued on `s`)
+static int build_f32_planes(mimc3_ctx *c, hipStream_t s)
+{
+    if (c->fplanes_ok) return 0;
+    const size_t bytes = sizeof(float) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
+    HIP_TRY(c->fpl0.reserve(bytes));
+    HIP_TRY(c->fpl1.reserve(bytes));
+    HIP_TRY(hipMemsetAsync(c->fpl0.p, 0, bytes, s));
+    HIP_TRY(hipMemsetAsync(c->fpl1.p, 0, bytes, s));
+    HIP_TRY(mimc3::launch_prep_f32(c->d_i0, c->H, c->W, static_cast<float *>(c->fpl0.p), c->Wp, mimc3::kU8Pad, s));
+    HIP_TRY(mimc3::launch_prep_f32(c->d_i1, c->H, c->W, static_cast<float *>(c->fpl1.p), c->Wp, mimc3::kU8Pad, s));
+    c->fplanes_ok = true;
+    return 0;
+}
+
 extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int32_t N, int32_t off_u, int32_t off_v,
                                        const int32_t *d_piv_uv, const int64_t *d_piv_off, int32_t max_npiv,
                                        int32_t max_abs_piv_u, int32_t max_abs_piv_v, int32_t ocw, int32_t swap,
@@ -506,16 +521,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
                 c->last_path = 3;
             }
         } else {
-            if (!c->fplanes_ok) {      // zero-bordered f32 copies of the pair, once per image pair
-                const size_t bytes = sizeof(float) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
-                HIP_TRY(c->fpl0.reserve(bytes));
-                HIP_TRY(c->fpl1.reserve(bytes));
-                HIP_TRY(hipMemsetAsync(c->fpl0.p, 0, bytes, s));
-                HIP_TRY(hipMemsetAsync(c->fpl1.p, 0, bytes, s));
-                HIP_TRY(mimc3::launch_prep_f32(c->d_i0, c->H, c->W, static_cast<float *>(c->fpl0.p), c->Wp, mimc3::kU8Pad, s));
-                HIP_TRY(mimc3::launch_prep_f32(c->d_i1, c->H, c->W, static_cast<float *>(c->fpl1.p), c->Wp, mimc3::kU8Pad, s));
-                c->fplanes_ok = true;
-            }
+            RC_TRY(build_f32_planes(c, s));
             u.p0 = static_cast<const unsigned char *>(c->fpl0.p); u.p1 = static_cast<const unsigned char *>(c->fpl1.p);
             e = mimc3::launch_match_f32x(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 2;
@@ -1093,6 +1099,10 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                 ch->no_u8o = true;
                 RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
                 ch->win_half = ocw_chip;
+                if (!ch->u8_ok && !ch->u16_ok) {       // float / 16-bit atlas: the f32 planes are built lazily by the first match
+                    RC_TRY(build_f32_planes(ch, ch->stream));   // -- here the four matches start on four streams, so build them first
+                    HIP_TRY(hipStreamSynchronize(ch->stream));
+                }
                 for (int c3 = 1; c3 < 3; c3++) {
                     const int ocw = p->vec_ocw[c3];
                     const int32_t slot = (c3 - 1) * 8 + v * 2;

@@ -56,6 +56,27 @@ def test_vs_oracle(api, oracle, name, seed):
         assert st == 1 and tuple(off) == CASES[name]["shift"]
 
 
+@pytest.mark.parametrize("seed", [3, 99])
+def test_16bit_pair_vs_oracle(api, oracle, seed):
+    """16-bit DN: the atlases of all four image variants take the register-tiled f32 kernel (16 concurrent matches on four
+    streams sharing each variant's f32 planes).  Integer DN keeps every f64 sum exact in any order, so votes are bit-identical."""
+    i0, i1 = synth.make_pair(620, 700, (2, -3), seed=31, null_frac=0.03, noise_dn=300, bits=16)
+    xy = synth.make_grid(24, 20, 60, 60, 24, 25, 1806.0, angle_deg=30.0)
+    rng = np.random.default_rng(5)
+    s = rng.random(xy.shape[0]) < 0.7
+    xy[s, 4] = rng.uniform(-5, 5, s.sum()); xy[s, 5] = rng.uniform(-5, 5, s.sum())
+    rc, off, flag, info, sduv = oracle.get_offset_image(i0, i1, xy, K, seed, num_cp_min=20)
+    with api.Context(0) as ctx:
+        ctx.set_images(i0, i1)
+        for _ in range(2):
+            st, o2, f2, info2, sduv2 = ctx.get_offset_image(xy, K, seed=seed, num_cp_min=20)
+            assert st == rc == 1
+            assert np.array_equal(info2, info), (info2, info)
+            assert np.array_equal(f2, flag)
+            assert np.array_equal(sduv2.view(np.uint32), sduv.view(np.uint32)), (sduv2, sduv)
+            assert np.array_equal(o2, off)
+
+
 def test_not_enough_candidates(api, oracle):
     i0, i1, xy = cp_case(seed=4, shift=(5, 5), slow=0.05)
     rc, off, flag, info, _ = oracle.get_offset_image(i0, i1, xy, K, 5, num_cp_min=20)
