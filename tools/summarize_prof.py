@@ -7,13 +7,23 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+
+
+def short(name):
+    """kernel names without the namespaces / argument lists, so that the template arguments stay visible"""
+    n = name.replace("void ", "").replace("mimc3::", "").replace("(anonymous namespace)::", "")
+    n = n.replace("match_ncc_dlc_px<PxCfg<", "px<").replace("> >(MatchU8Args)", ">").replace("(MatchArgs)", "")
+    i = n.find("(")
+    return (n[:i] if i > 0 and not n.startswith("px<") else n).replace(", ", ",")
+
+
 print(f"# rocprofv3 summary for {os.path.basename(out)}")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("\n## kernel stats (--kernel-trace --stats):", os.path.relpath(f, out))
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
-    for r in rows[:12]:
-        print("  {Name:60.60s} calls={Calls:>5s} total_ns={TotalDurationNs:>12s} avg_ns={AverageNs:>12s} pct={Percentage}".format(**r))
+    for r in rows[:40]:
+        print("  {0:44.44s} calls={Calls:>5s} total_ns={TotalDurationNs:>12s} avg_ns={AverageNs:>14s} pct={Percentage}".format(short(r["Name"]), **r))
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
@@ -24,7 +34,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for k, v in by.items():
         r = v[0]
         keys = [c for c in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if c in r]
-        print("  %-60.60s " % k + " ".join(f"{c}={r[c]}" for c in keys))
+        print("  %-44.44s " % short(k) + " ".join(f"{c}={r[c]}" for c in keys))
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -37,4 +47,4 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         print(f"\n## PMC {os.path.basename(d)} (mean per dispatch)")
         for k, cs in acc.items():
             for c, vals in cs.items():
-                print("  %-50.50s %-24s n=%d mean=%.6g" % (k, c, len(vals), sum(vals) / len(vals)))
+                print("  %-44.44s %-24s n=%d mean=%.6g max=%.6g" % (short(k), c, len(vals), sum(vals) / len(vals), max(vals)))
