@@ -310,6 +310,9 @@ int mimc3_ctx_device(mimc3_ctx *ctx);
  *      bytes; freed with the context.  The drivers above the ABI (mimc3_postprocess, mimc3_vmap) keep their working
  *      buffers here instead of allocating per call.  One stream at a time per context. */
 int mimc3_ctx_workspace(mimc3_ctx *ctx, int32_t slot, size_t bytes, void **d_ptr);
+/*      one of the context's four auxiliary hipStream_t (k = 0..3; created with the context -- creating a stream while
+ *      kernels run costs milliseconds): the drivers' host threads upload on them next to the context's own stream. */
+void *mimc3_ctx_aux_stream(mimc3_ctx *ctx, int32_t k);
 /*      the same for PINNED host memory (slot 0..7): pinning pages costs milliseconds per tens of MB, so the drivers keep
  *      their staging buffers (the pivot lists of the 32 passes) across calls.  Distinct slots may be asked for from
  *      distinct host threads at the same time. */

@@ -81,6 +81,8 @@ struct mimc3_ctx {
     bool filt_live = false;             // filt0/filt1 hold the output planes of an earlier filter pass on this pair
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // CP stage: its 16 small matcher launches per segment overlap on 4 streams
     hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // mimc3_ctx_aux_stream: copy streams of the drivers' host threads
+    bool child = false;                 // a control-point child context: no streams / children of its own beyond `stream`
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -189,7 +191,11 @@ static float min_dn_threshold()
 extern "C" const char *mimc3_last_error(void) { return mimc3::g_err.c_str(); }
 extern "C" const char *mimc3_version(void) { return "mimc3_hip 0.1.0 (gfx950)"; }
 
-extern "C" int mimc3_ctx_create(int device, mimc3_ctx **out)
+static int ctx_create_impl(int device, mimc3_ctx **out, bool child);
+
+extern "C" int mimc3_ctx_create(int device, mimc3_ctx **out) { return ctx_create_impl(device, out, false); }
+
+static int ctx_create_impl(int device, mimc3_ctx **out, bool child)
 {
     if (!out) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_create: out is NULL");
     *out = nullptr;
@@ -204,8 +210,22 @@ extern "C" int mimc3_ctx_create(int device, mimc3_ctx **out)
     if (e != hipSuccess) { delete c; return mimc3::hip_fail(e, "hipStreamCreate"); }
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
+    c->child = child;
+    if (!child) {
+        // everything the control-point stage and the drivers' host threads need later is created NOW, on an idle device:
+        // hipStreamCreate / hipStreamDestroy take milliseconds each while kernels are running (measured 3-8 ms)
+        for (auto &st : c->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (auto &st : c->aux) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (auto &ev : c->ev_side) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        for (auto &ch : c->cp_child) (void)ctx_create_impl(device, &ch, true);
+    }
     *out = c;
     return 0;
+}
+
+extern "C" void *mimc3_ctx_aux_stream(mimc3_ctx *c, int32_t k)
+{
+    return (c && k >= 0 && k < 4) ? static_cast<void *>(c->aux[k]) : nullptr;
 }
 
 extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
@@ -228,6 +248,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     for (auto &pp : c->pin) if (pp) (void)hipHostFree(pp);
     for (auto &ev : c->ev_pin) if (ev) (void)hipEventDestroy(ev);
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
+    for (auto &st : c->aux) if (st) (void)hipStreamDestroy(st);
     for (auto &ev : c->ev_side) if (ev) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1029,7 +1050,7 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     int32_t *d_ncl = ar.take<int32_t>(nm);
     int32_t *d_kmax = ar.take<int32_t>(1);
     HIP_TRY(mimc3::launch_cp_fill_problem(d_xy, d_piv, d_poff, nmax, awc, ocw_chip, cs, s));
-    for (auto &ch : c->cp_child) if (!ch) RC_TRY(mimc3_ctx_create(c->device, &ch));
+    for (auto &ch : c->cp_child) if (!ch) RC_TRY(ctx_create_impl(c->device, &ch, true));
 
     clk.mark("setup + uploads");
     float sduv[2] = {0.0f, 0.0f};

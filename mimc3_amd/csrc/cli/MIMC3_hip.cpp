@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <thread>
 #include <unistd.h>
 #include <tiffio.h>
@@ -149,6 +150,15 @@ int main(int argc, char *argv[])
     p.cp_seed = seed ? atoll(seed) : -1;
     p.qm_max_sweeps = 101;
 
+    // MIMC3_CLI_TIMING=1: wall time of each step on stderr
+    const bool timing = getenv("MIMC3_CLI_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[MIMC3_hip] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // ---- inputs (:200-230)
     std::vector<double> xy;
     int32_t N = 0, ncol = 0;
@@ -176,8 +186,11 @@ int main(int argc, char *argv[])
     });
     auto cleanup = [&]() { if (ctx) mimc3_ctx_destroy(ctx); if (mg) mimc3_mgpu_destroy(mg); ctx = nullptr; mg = nullptr; };
     RawImage i0, i1;
+    lap("xyuvav read");
     const bool tiff_ok = load_tiff(argv[1], i0) && load_tiff(argv[2], i1);
+    lap("TIFF decode");
     ctx_thread.join();
+    lap("device context (rest of)");
     if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); cleanup(); return 2; }
     if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); cleanup(); return 2; }
     if (ctx_rc) { fprintf(stderr, "%s\n", ctx_err.c_str()); return 3; }
@@ -198,6 +211,7 @@ int main(int argc, char *argv[])
         rc = mg ? mimc3_mgpu_set_images(mg, f0.data(), f1.data(), H, W) : mimc3_ctx_set_images(ctx, f0.data(), f1.data(), H, W);
     }
     if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); cleanup(); return 3; }
+    lap("pair upload");
 
     std::vector<float> vx(N), vy(N), ex(N), ey(N), qual(N);
     std::vector<uint8_t> flag(N);
@@ -209,8 +223,10 @@ int main(int argc, char *argv[])
         cleanup();
         return 3;
     }
+    lap("vmap (data path)");
     if (mg) printf("grid points sharded over %d GPU(s), work imbalance %.1f %%\n", (int)mimc3_mgpu_ndev(mg), 100.0 * mimc3_mgpu_last_imbalance(mg));
-    cleanup();
+    // (no teardown on the way out: freeing the device buffers and the HIP runtime's exit handlers cost 50+ ms and the
+    //  process is about to end -- the outputs are written, then the process leaves through _exit)
     printf("MPP=%f, grid spacing=%f, meter per spacing=%fm\nDimension of the vmap: %d by %d (mapy / mapx)\n", r.mpp, r.spacing_grid,
            r.meter_per_spacing, r.dimy, r.dimx);
     if (r.cp_status < 0) {                                                              // :246-252
@@ -237,6 +253,9 @@ int main(int argc, char *argv[])
         ok = fclose(fm) == 0 && ok;
     } else ok = false;
     if (!ok) { fprintf(stderr, "could not write the outputs under %s\n", argv[4]); return 4; }
+    lap("outputs written");
     printf("Processing completed\n");
-    return 0;
+    fflush(nullptr);
+    if (getenv("MIMC3_CLI_TEARDOWN")) { cleanup(); return 0; }     // (leak checkers)
+    _exit(0);
 }

@@ -79,7 +79,7 @@ int nccl_fail(int e, const char *what)
 #define RC_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 #define NCCL_TRY(expr) do { int e_ = (expr); if (e_ != 0) return nccl_fail(e_, #expr); } while (0)
 
-// context scratch slots used here (pipeline.cpp owns 0..5)
+// context scratch slots used here (pipeline.cpp owns 0..5 and 11..14)
 enum { kSlotLocal = 6, kSlotGather = 7, kSlotPerm = 8, kSlotFull = 9, kSlotMatchIo = 10 };
 
 struct mimc3_mgpu {

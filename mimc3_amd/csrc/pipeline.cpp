@@ -25,7 +25,7 @@
 namespace {
 
 // context scratch slots (mimc3_ctx_workspace) used by the drivers in this file and in mgpu.cpp
-enum { kSlotPost = 0, kSlotXy = 1, kSlotPiv = 2, kSlotOut5 = 3, kSlotDp = 4, kSlotXyFull = 5 };
+enum { kSlotPost = 0, kSlotXy = 1, kSlotOut5 = 3, kSlotDp = 4, kSlotXyFull = 5, kSlotPiv0 = 11 /* ..14: one per chip size */ };
 
 // a typed view of a piece of context scratch
 struct View {
@@ -158,6 +158,25 @@ int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, flo
     // the four chip sizes are independent: one host thread each (every one of them fans out again inside mimc3_get_uv_pivot)
     int rcs[4] = {0, 0, 0, 0};
     std::string errs[4];
+    // device copies: forward and negated (:272-279) pivots + offsets, on a stream of this thread's own
+    auto upload = [&](int c) -> int {
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t tb = 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), ob = 8 * ((size_t)ns + 1);
+        void *base = nullptr;
+        RC_TRY(mimc3_ctx_workspace(ctx, kSlotPiv0 + c, 2 * al(tb) + al(ob), &base));      // (also selects the context's device for this thread)
+        char *cur = static_cast<char *>(base);
+        hp[c].d_uv = reinterpret_cast<int32_t *>(cur); cur += al(tb);
+        hp[c].d_uvn = reinterpret_cast<int32_t *>(cur); cur += al(tb);
+        hp[c].d_off = reinterpret_cast<int64_t *>(cur);
+        hipStream_t st = static_cast<hipStream_t>(mimc3_ctx_aux_stream(ctx, c));
+        if (!st) return mimc3::fail(MIMC3_ESTATE, "mimc3_vmap: the context has no auxiliary stream");
+        hipError_t e = hipMemcpyAsync(hp[c].d_uv, hp[c].uv, 8 * (size_t)hp[c].total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(hp[c].d_off, hp[c].off.data(), ob, hipMemcpyHostToDevice, st);
+        int rc = e == hipSuccess ? mimc3_negate_pivots_dev(ctx, hp[c].d_uv, hp[c].d_uvn, hp[c].total, st) : hip_fail(e, "pivot upload");
+        e = hipStreamSynchronize(st);
+        if (!rc && e != hipSuccess) rc = hip_fail(e, "pivot upload");
+        return rc;
+    };
     auto one = [&](int c) {
         hp[c].off.resize((size_t)ns + 1);
         int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
@@ -165,6 +184,7 @@ int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, flo
         if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
                                          static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
         if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
+        if (!rc) rc = upload(c);
         if (rc) { errs[c] = mimc3_last_error(); rcs[c] = rc; }          // the message is thread-local: carry it over
     };
     if (ns >= 20000) {
@@ -219,26 +239,15 @@ int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t 
     RC_TRY(mimc3_ctx_workspace(ctx, kSlotXy, 48 * n, &d_xy));
     HIP_TRY(hipMemcpyAsync(d_xy, xs, 48 * n, hipMemcpyHostToDevice, s));
 
-    // ---- pivots: forward and negated (:272-279) copies resident for all four image variants (one scratch slot)
+    // ---- pivots: forward and negated copies are resident already (uploaded by vmap_host_pivots' threads)
     struct Piv { int32_t *uv, *uvn; int64_t *off; };
     Piv piv[4];
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t need = 0;
-    for (int c = 0; c < 4; c++) need += 2 * al(8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1)) + al(8 * (n + 1));
-    void *pbase = nullptr;
-    RC_TRY(mimc3_ctx_workspace(ctx, kSlotPiv, need, &pbase));
-    char *cur = static_cast<char *>(pbase);
     for (int c = 0; c < 4; c++) {
-        const size_t tb = 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1);
-        piv[c].uv = reinterpret_cast<int32_t *>(cur); cur += al(tb);
-        piv[c].uvn = reinterpret_cast<int32_t *>(cur); cur += al(tb);
-        piv[c].off = reinterpret_cast<int64_t *>(cur); cur += al(8 * (n + 1));
-        HIP_TRY(hipMemcpyAsync(piv[c].uv, hp[c].uv, 8 * (size_t)hp[c].total, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(piv[c].off, hp[c].off.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
-        RC_TRY(mimc3_negate_pivots_dev(ctx, piv[c].uv, piv[c].uvn, hp[c].total, s));
+        if (!hp[c].d_uv || !hp[c].d_off) return mimc3::fail(MIMC3_ESTATE, "mimc3_vmap: pivots were not uploaded");
+        piv[c] = {hp[c].d_uv, hp[c].d_uvn, hp[c].d_off};
     }
     HIP_TRY(hipStreamSynchronize(s));
-    clk.mark("pivots: upload", s);
+    clk.mark("grid upload", s);
     // ---- 32 matcher passes (:261-350): variant -1 = the pair as loaded, 0..2 = the three filters
     for (int kk = -1; kk <= 2; kk++) {
         if (kk >= 0) {

@@ -8,11 +8,15 @@
 
 namespace mimc3 {
 
-// host CSR pivots of one chip size for a set of points; payload in the context's pinned host scratch
+// CSR pivots of one chip size for a set of points: made on the host (payload in the context's pinned host scratch) and
+// uploaded from the same thread, so that all of it overlaps the control-point stage
 struct HostPivots {
     std::vector<int64_t> off;
     void *uv = nullptr;
     int64_t total = 0;
+    // device copies in the context's scratch (uploaded by the thread that made them): pivots, negated pivots (:272-279), offsets
+    int32_t *d_uv = nullptr, *d_uvn = nullptr;
+    int64_t *d_off = nullptr;
     int32_t mn = 0, mu = 0, mv = 0;
     HostPivots() = default;
     HostPivots(const HostPivots &) = delete;

@@ -38,6 +38,8 @@ def main():
     os.makedirs(f"{d}/hip"); os.makedirs(f"{d}/ref")
     t = time.time()
     p = subprocess.run([CLI] + args + [f"{d}/hip"], env=dict(os.environ, MIMC3_CP_SEED="7"), capture_output=True, text=True)
+    if os.environ.get("MIMC3_CLI_TIMING"):
+        sys.stderr.write(p.stderr)
     res["cli_wall_s"] = time.time() - t
     res["cli_rc"] = p.returncode
     if p.returncode != 0:
