@@ -892,6 +892,25 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
         return !(pu - OCW <= 1 || pu + OCW >= pt.Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= pt.Dy2 - 1);
     };
+    // One scan of the reference's 3x3 loop (:719-741) on the cached values around centre (cu, cv), from running maximum `sm`:
+    // returns -2 if a cell is not evaluated yet, else the 3x3 index that took the maximum (-1: none did) and the new `sm`.
+    // The sequential "if (v > max) { max = v; arg = j; }" ends on the FIRST cell that attains the overall maximum, if that
+    // exceeds the old one; NaN never wins (max3 skips NaNs like the compare does).  Unknown / wanted cells hold 3.0 / 4.0,
+    // above every NCC, so one maximum answers "all known?" as well.
+    auto scan9 = [&](int cu, int cv, float &sm) __attribute__((always_inline)) -> int {
+        float v[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) v[j] = lookup(cu + (j / 3 - 1) - OCW, cv + (j % 3 - 1) - OCW);
+        const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]), __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5])),
+                                        __builtin_fmaxf(__builtin_fmaxf(v[6], v[7]), v[8]));
+        if (m >= 2.5f) return -2;
+        if (!(m > sm)) return -1;
+        int mv = 8;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) mv = (v[j] == m) ? j : mv;
+        sm = m;
+        return mv;
+    };
     // request the whole 3x3 around compact cell (cx0, cy0): the nine compare-and-swaps are issued together, one bump of
     // the packed counter reserves the queue entries of the cells this lane won
     auto request9 = [&](int cx0, int cy0) __attribute__((always_inline)) {
@@ -1134,16 +1153,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // further in the direction it just moved (lookahead: straight climbs advance 2 scans per batch)
             int ldu = 0, ldv = 0;
             while (alive && !cut && nsc < kSpecRounds) {
-                int mv = -1;
                 float sm = smax;
-                bool known = true;
-#pragma unroll
-                for (int j = 0; j < 9; j++) {
-                    const float v = lookup(su + (j / 3 - 1) - OCW, sv + (j % 3 - 1) - OCW);
-                    known = known && !(v >= 2.5f);                  // 3.0 / 4.0 = not evaluated yet (NaN is a value)
-                    if (v > sm) { sm = v; mv = j; }                 // NaN never wins (:736)
-                }
-                if (!known) break;                                   // wait for the batch that holds the missing cells
+                const int mv = scan9(su, sv, sm);
+                if (mv == -2) break;                                 // wait for the batch that holds the missing cells
                 smax = sm;
                 const bool moved = (mv >= 0 && mv != 4);
                 ldu = moved ? mv / 3 - 1 : 0; ldv = moved ? mv % 3 - 1 : 0;
@@ -1173,16 +1185,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     unsigned long long tr = 0ull;
                     int n = 0;
                     while (go && n < kSpecRounds) {
-                        int mv = -1;
                         float sm = em;
-                        bool known = true;
-#pragma unroll
-                        for (int jj = 0; jj < 9; jj++) {
-                            const float v = lookup(eu + (jj / 3 - 1) - OCW, ev + (jj % 3 - 1) - OCW);
-                            known = known && !(v >= 2.5f);
-                            if (v > sm) { sm = v; mv = jj; }
-                        }
-                        if (!known) { request9(eu - OCW, ev - OCW); stalled = true; break; }
+                        const int mv = scan9(eu, ev, sm);
+                        if (mv == -2) { request9(eu - OCW, ev - OCW); stalled = true; break; }
                         em = sm;
                         const bool moved = (mv >= 0 && mv != 4);
                         if (moved) { eu += mv / 3 - 1; ev += mv % 3 - 1; }
