@@ -925,10 +925,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         for (int j = 0; j < 9; j++)
             if (old[j] == kUnknownBits) won |= 1u << j;
         if (!won) return;
-        uint32_t cl = 0;
+        // clean boxes of the 3x3 from three column tests and three row tests (bit j = 3 * column + row, as above): a box is
+        // clean if its column range or its row range misses the null bounding box, and it does not touch the T4 row / column
+        uint32_t row_ok = 0u, row_t4 = 0u;
 #pragma unroll
-        for (int j = 0; j < 9; j++)
-            if (((won >> j) & 1u) && box_clean(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1))) cl |= 1u << j;
+        for (int k = 0; k < 3; k++) {
+            const int cy = cy0 + k - 1;
+            row_ok |= (win_clean || cy > nby1 || cy + CW - 1 < nby0) ? (1u << k) : 0u;
+            row_t4 |= (!full_win && cy == pt.csy - 2) ? (1u << k) : 0u;
+        }
+        uint32_t cl = 0u;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int cx = cx0 + i - 1;
+            const bool col_ok = win_clean || cx > nbx1 || cx + CW - 1 < nbx0;
+            const bool col_t4 = !full_win && cx == pt.csx - 2;
+            const uint32_t part = col_t4 ? 0u : ((col_ok ? 7u : row_ok) & ~row_t4);
+            cl |= part << (3 * i);
+        }
         const uint32_t wa = won & cl, wb = won & ~cl;
         const int na = __popc(wa), nb = __popc(wb);
         const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], na | (nb << 16));
