@@ -21,6 +21,7 @@
 //   * per-cell modes FAST / CHIPNULL / GENERAL (null handling), slot-mapped NCC cache, speculative
 //     parallel climb + exact replay of the reference's sequential hill climb (:691-753): see DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
@@ -658,30 +659,35 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         }
         // The row walk is a chain of global loads: eight rows are fetched before any of them is used (one memory latency per
         // eight rows instead of one per row), and the rare null handling runs after the batch on the values in registers.
+        // (32-bit dword offsets from the point's uniform base: one add per load instead of a 64-bit multiply-add; whole
+        //  batches of eight rows carry no bounds tests, only the last partial batch does)
+        const uint32_t gstep = (uint32_t)(rstep * (P::SRC16 ? gpitch16 : gpitch));     // dwords (uint2s) between this thread's rows
+        const int wstep = rstep * pt.PW;
         if (col_on)
         for (int c = c_first; c < nd; c += cstep) {
             const uint32_t keep = col_keep(c);
             const int x0 = P::G * c - pt.sh;                              // window column of the dword's first pixel
             bool hit = false;                                             // this column holds excluded pixels (x range of the null box)
             constexpr int KB = 8;
-            for (int rb = r0; rb < wrows; rb += KB * rstep) {
+            auto batch = [&](auto tail_c, int rb) __attribute__((always_inline)) {
+                constexpr bool TAIL = decltype(tail_c)::value;
                 uint32_t v[KB];
                 [[maybe_unused]] uint2 v16[KB];
+                const uint32_t g0 = (uint32_t)rb * (uint32_t)(P::SRC16 ? gpitch16 : gpitch) + (uint32_t)c;
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
-                    const int r = rb + k * rstep;
-                    const int rl = r < wrows ? r : rb;                    // rows past the end re-read the batch's first row (discarded)
-                    if constexpr (P::SRC16) v16[k] = gbase16[(size_t)rl * gpitch16 + c];
-                    else v[k] = gbase[(size_t)rl * gpitch + c];
+                    const uint32_t gi = (TAIL && rb + k * rstep >= wrows) ? g0 : g0 + (uint32_t)k * gstep;   // rows past the end re-read the batch's first row (discarded)
+                    if constexpr (P::SRC16) v16[k] = gbase16[gi];
+                    else v[k] = gbase[gi];
                 }
+                unsigned char *wp = W + rb * pt.PW + 4 * c;
                 bool susp = false;
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
-                    const int r = rb + k * rstep;
                     if constexpr (P::SRC16) v[k] = PxU8o::pack(v16[k], kb);
                     v[k] &= keep;                                         // pixels outside the written columns -> 0 (covers T4 column)
-                    if (r < wrows) {
-                        *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = v[k];
+                    if (!TAIL || rb + k * rstep < wrows) {
+                        *reinterpret_cast<uint32_t *>(wp + k * wstep) = v[k];
                         susp = susp || P::maybe_excl(v[k], keep, pt.thr);
                     }
                 }
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                     for (int k = 0; k < KB; k++) {
                         const int r = rb + k * rstep;
-                        if (r >= wrows || !P::maybe_excl(v[k], keep, pt.thr)) continue;
+                        if ((TAIL && r >= wrows) || !P::maybe_excl(v[k], keep, pt.thr)) continue;
                         bad_win += P::nbad(v[k], keep, pt.thr);
                         const int nz = P::nexcl(v[k], keep, pt.thr);
                         exc_win += nz;
@@ -709,7 +715,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                     }
                 }
-            }
+            };
+            int rb = r0;
+            for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, rb);
+            if (rb < wrows) batch(std::true_type{}, rb);
             if (hit) { nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); }
         }
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
