@@ -1235,6 +1235,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             stage = kSpecRounds;
             if (qcnt[0] != 0) return 0;                             // evaluate what was queued first
         }
+        if (p.debug_stop == 7) return 1;                             // (profiling: everything but the replay and the fit)
         if (!replay_generic) {
             // ---- exact replay from the recorded trajectories.  Every scan's move and running maximum
             //      depend only on NCC values (identical to the reference's compare sequence, :736-741);
@@ -1273,27 +1274,30 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 for (int t = 0; t < kSpecRounds; t++) {
                     const int code = (int)((tr >> (4 * t)) & 15ull);
                     if (code == 0 || !cont) break;
-                    int unv = 0;
+                    bool unv;                        // (kept as a lane-mask test: no 0/1 value goes through a vector register)
                     if (regmask) {
                         // the three rows ccy-1..ccy+1 test and set their own 3 bits in parallel
                         const int ccx = qu - OCW, ccy = qv - OCW;
                         const unsigned long long m3 = 7ull << (ccx - 1);
+                        const uint32_t m3lo = (uint32_t)m3, m3hi = (uint32_t)(m3 >> 32);
                         const bool mine = (unsigned)(lane - (ccy - 1)) < 3u;
-                        const unsigned long long m = ((unsigned long long)vhi << 32) | vlo;
-                        unv = __any(mine && ((~m & m3) != 0ull)) ? 1 : 0;
-                        const unsigned long long mn = m | m3;
-                        vlo = mine ? (uint32_t)mn : vlo;
-                        vhi = mine ? (uint32_t)(mn >> 32) : vhi;
+                        unv = __ballot(mine && (((~vlo & m3lo) | (~vhi & m3hi)) != 0u)) != 0ull;
+                        vlo = mine ? (vlo | m3lo) : vlo;
+                        vhi = mine ? (vhi | m3hi) : vhi;
                     } else {
                         const int vb = (lane < 9) ? (qv + c2 - OCW) * vpitch + (qu + c1 - OCW) : 0;
                         const bool unvis = (lane < 9) && (((vis[vb >> 5] >> (vb & 31)) & 1u) == 0u);
-                        unv = __popcll(__ballot(unvis));
+                        unv = __ballot(unvis) != 0ull;
                         if (unvis) atomicOr(&vis[vb >> 5], 1u << (vb & 31));
                     }
                     Tk = t + 1;
                     const bool moved = (code <= 9) && (code != 5);
-                    if (moved) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; qu += q3 - 1; qv += (mv - 3 * q3) - 1; }
-                    cont = moved && (unv != 0);
+                    if (moved) {                     // 3x3 index code-1 -> (column, row) step; the quotient by 3 from a 2-bit table (scalar)
+                        const int mv = code - 1;
+                        const int q3 = (int)((0x2A540u >> (2 * mv)) & 3u);
+                        qu += q3 - 1; qv += (mv - 3 * q3) - 1;
+                    }
+                    cont = moved && unv;
                 }
                 if (!C::MANYP || kk < 64) {
                     if (lane == kk) T = Tk;
@@ -1406,7 +1410,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         return;
     }
     MIMC3_STAMP(3)
-    if (p.debug_stop == 6) { if (tid == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
+    if (p.debug_stop == 6 || p.debug_stop == 7) { if (tid == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
     // ---- 3x3 quadratic fit (:757-788) ----------------------------------------------------------
     if (tid == 0) {
         float n9[9];

@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/pmc_phases
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for k in 1 2 3 4 6 0; do
+for k in 1 2 3 4 7 6 0; do     # 1 window staged, 2 + chip, 3 + certain-set requests, 4 + their evaluation, 7 + speculative climb (and its evaluations), 6 + replay, 0 + fit
   MIMC3_U8_DEBUG_STOP=$k rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/stop$k -o pmc -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-program --no-f32-path --qm-sweeps 0 > /dev/null 2> $OUT/stop$k.err || echo "stop $k failed"
   python3 - "$OUT/stop$k/pmc_counter_collection.csv" $k <<'PY'
 import csv, sys, collections
