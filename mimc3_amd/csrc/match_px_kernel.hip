@@ -262,21 +262,35 @@ struct PxU8o : PxU8 {
         const double den = sqrt((dn * sxx - sx * sx) * (dn * syy - sy * sy));
         return (float)(num / den);
     }
-    // four u16 pixels (two dwords) -> four u8 pixels q - k (0 stays 0); bytes are confined even when q - k is out of range
+    // four u16 pixels (two dwords) -> four u8 pixels q - k (0 stays 0); bytes are confined even when q - k is out of range.
+    // Packed 16-bit arithmetic: (q - k) * min(q, 1) per half-word, then one byte permute gathers the four low bytes.
+    __device__ static __forceinline__ us2_t as_us2(uint32_t v) { return __builtin_bit_cast(us2_t, v); }
+    __device__ static __forceinline__ uint32_t as_u32(us2_t v) { return __builtin_bit_cast(uint32_t, v); }
     __device__ static __forceinline__ uint32_t pack(uint2 v, int k)
     {
-        const uint32_t q0 = v.x & 0xffffu, q1 = v.x >> 16, q2 = v.y & 0xffffu, q3 = v.y >> 16;
-        const uint32_t b0 = q0 ? ((q0 - (uint32_t)k) & 0xffu) : 0u, b1 = q1 ? ((q1 - (uint32_t)k) & 0xffu) : 0u;
-        const uint32_t b2 = q2 ? ((q2 - (uint32_t)k) & 0xffu) : 0u, b3 = q3 ? ((q3 - (uint32_t)k) & 0xffu) : 0u;
-        return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        const us2_t kk = {(unsigned short)k, (unsigned short)k}, one = {1, 1};
+        const us2_t x = as_us2(v.x), y = as_us2(v.y);
+        const us2_t dx = (x - kk) * __builtin_elementwise_min(x, one), dy = (y - kk) * __builtin_elementwise_min(y, one);
+        return __builtin_amdgcn_perm(as_u32(dy), as_u32(dx), 0x06040200u);
     }
-    // min / max over the non-null pixels of four u16 pixels selected by the byte mask `keep`
-    __device__ static __forceinline__ void range4(uint2 v, uint32_t keep, int &mn, int &mx)
+    // running min / max (two packed 16-bit lanes each; empty = 0xffff / 0) over the non-null pixels of four u16 pixels
+    // selected by the byte mask `keep` (0x00 / 0xff per pixel)
+    struct Range2 { us2_t mn, mx; };
+    __device__ static __forceinline__ Range2 range_empty() { return Range2{us2_t{0xffff, 0xffff}, us2_t{0, 0}}; }
+    __device__ static __forceinline__ void range4(uint2 v, uint32_t keep, Range2 &r)
     {
-        const uint32_t q[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (((keep >> (8 * i)) & 0xffu) && q[i]) { mn = min(mn, (int)q[i]); mx = max(mx, (int)q[i]); }
+        const us2_t one = {1, 1};
+        const uint32_t kx = __builtin_amdgcn_perm(keep, keep, 0x01010000u), ky = __builtin_amdgcn_perm(keep, keep, 0x03030202u);
+        const us2_t x = as_us2(v.x & kx), y = as_us2(v.y & ky);
+        r.mx = __builtin_elementwise_max(r.mx, __builtin_elementwise_max(x, y));
+        // pixels that do not count (null or not kept) are 0 here: raise them to 0xffff for the minimum
+        const us2_t fx = as_us2(as_u32(x) | as_u32(__builtin_elementwise_min(x, one) - one)), fy = as_us2(as_u32(y) | as_u32(__builtin_elementwise_min(y, one) - one));
+        r.mn = __builtin_elementwise_min(r.mn, __builtin_elementwise_min(fx, fy));
+    }
+    __device__ static __forceinline__ void range_out(const Range2 &r, int &mn, int &mx)     // -> the scalar convention: empty = (1 << 20, -1)
+    {
+        const int a = min((int)r.mn.x, (int)r.mn.y), b = max((int)r.mx.x, (int)r.mx.y);
+        mn = (b == 0) ? (1 << 20) : a; mx = (b == 0) ? -1 : b;
     }
 };
 
@@ -603,6 +617,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // pass 1: local range of the window and of the chip; a point that does not fit 8 bits goes to the u16 kernel
             // (both scans fetch eight values before they use any: the loops are chains of global loads otherwise)
             int mn = 1 << 20, mx = -1;
+            PxU8o::Range2 rw = PxU8o::range_empty();
             if (col_on)
                 for (int c = c_first; c < nd; c += cstep) {
                     const uint32_t keep = col_keep(c);
@@ -611,10 +626,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                         for (int k = 0; k < 8; k++) { const int r = rb + k * rstep; t[k] = gbase16[(size_t)(r < wrows ? r : rb) * gpitch16 + c]; }
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (rb + k * rstep < wrows) PxU8o::range4(t[k], keep, mn, mx);
+                        for (int k = 0; k < 8; k++) if (rb + k * rstep < wrows) PxU8o::range4(t[k], keep, rw);
                     }
                 }
+            PxU8o::range_out(rw, mn, mx);
             int cmn = 1 << 20, cmx = -1;
+            PxU8o::Range2 rc = PxU8o::range_empty();
             {
                 // the chip as aligned 4-pixel groups: row rr, group cc of the (GPR + 1) groups that cover its CW pixels
                 const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
@@ -637,10 +654,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         uint32_t keep = 0u;
 #pragma unroll
                         for (int b = 0; b < 4; b++) { const int col = 4 * cc[k] + b - cph; if (col >= 0 && col < CW) keep |= 0xffu << (8 * b); }
-                        PxU8o::range4(t[k], keep, cmn, cmx);
+                        PxU8o::range4(t[k], keep, rc);
                     }
                 }
             }
+            PxU8o::range_out(rc, cmn, cmx);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64));
