@@ -393,6 +393,23 @@ struct PxCfg {
     // their own; their speculative climbs are recorded in LDS so that the exact replay stays on the fast form.  A separate
     // instantiation: the plain configurations keep their register allocation.
     static constexpr bool MANYP = MANY_;
+    // Tail tasks without masks (sparse-correction configs): a tail dword is all chip pixels except the LAST dword of a
+    // chip row, whose pad bytes carry no pixel.  If no lane owns more than one such dword, the evaluation runs every tail
+    // task with a full mask and takes the pad pixels of that one dword out again (one extra dword per lane and cell)
+    // instead of deriving a byte mask from the chip dword in every tail task.
+    static constexpr bool one_pad_task_per_lane()
+    {
+        for (int ln = 0; ln < LPC_; ln++) {
+            int cnt = 0;
+            for (int k = 0; k < TT; k++) {
+                const int tt = ln + LPC_ * k;
+                if (tt < REM * GPR && tt % GPR == GPR - 1) cnt++;
+            }
+            if (cnt > 1) return false;
+        }
+        return true;
+    }
+    static constexpr bool FULLTAIL = SPARSE && !CHIP_LDS && TT >= 4 && LASTN < P::G && one_pad_task_per_lane();   // (measured: no gain for the chip-from-LDS u16 ocw 40 form, a loss with one tail task: ocw 32)
 };
 static constexpr int kLwCap = 1024;    // window-null list entries (x | y << 16); more -> the point falls back to GENERAL
 static constexpr int kLcCap = 512;     // chip-null list entries
@@ -407,7 +424,7 @@ struct U8Point {
 
 // One evaluation round: lane group g (LPC lanes) evaluates the cell whose chip origin in window
 // coordinates is (cx, cy) (== compact cell coordinates).  Returns group-reduced sums in every lane.
-template <class C, int MODE, bool REDUCE = true>
+template <class C, int MODE, bool REDUCE = true, bool FULLTAIL = false>
 __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned char *W, const U8Point &pt, int cx, int cy, int l,
                                           const uint32_t (&A)[C::RF > 0 ? C::RF : 1][C::GPR],
                                           const uint32_t (&AT)[C::TT > 0 ? C::TT : 1],
@@ -477,7 +494,14 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
             const int tt = l + C::LPC * k;
             av = tt < C::REM * C::GPR ? *reinterpret_cast<const volatile uint32_t *>(CH + (C::RF * C::LPC + tt / C::GPR) * C::CPITCH + 4 * (tt % C::GPR)) : 0u;
         }
-        P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
+        if constexpr (FULLTAIL && MODE == M_FAST) {
+            // full mask: the caller corrects for pad pixels and lists the tail rows' nulls.  Only the last task has lanes
+            // without a dword (they hold a zero chip dword but would still read a window dword): their window is zeroed.
+            uint32_t bwt = bw;
+            if (k == C::TT - 1 && (C::REM * C::GPR) % C::LPC != 0) bwt = (l + C::LPC * k < C::REM * C::GPR) ? bw : 0u;
+            P::template task<M_FAST, C::OPQ>(acc, av, P::BPP == 1 ? 0x01010101u : 0x00010001u, 0xffffffffu, true, bwt, pt.thr);
+        }
+        else P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
     }
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
@@ -769,6 +793,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     constexpr int RFA = C::RF > 0 ? C::RF : 1, TTA = C::TT > 0 ? C::TT : 1;
     uint32_t A[RFA][GPR], AT[TTA];
     int toff[TTA];
+    int padoff = -1;                                         // FULLTAIL configs: LDS offset of this lane's row-end tail dword (or none)
     int bad_chip = 0, exc_chip = 0;
     bool chip_susp = false;                                  // some chip dword of this lane may hold a null (integer policies: counted afterwards)
     Sum SX = 0, SXX = 0;
@@ -820,6 +845,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
+            if (C::FULLTAIL && on && j == GPR - 1) padoff = toff[k];
             P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
                 if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
@@ -858,7 +884,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const bool on = tt < C::REM * GPR;
                 const int j = on ? tt % GPR : 0;
                 const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
-                if (P::maybe_excl(AT[k], pff, pt.thr)) { bad_chip += P::nbad(AT[k], pff, pt.thr); exc_chip += P::nexcl(AT[k], pff, pt.thr); }
+                if (P::maybe_excl(AT[k], pff, pt.thr)) {
+                    bad_chip += P::nbad(AT[k], pff, pt.thr);
+                    const int nzc = P::nexcl(AT[k], pff, pt.thr);
+                    exc_chip += nzc;
+                    if constexpr (C::FULLTAIL) {             // maskless tail tasks: the tail rows' nulls are corrected from the list too
+                        if (wave == 0 && on && nzc) {
+                            int at = atomicAdd(&qcnt[17], nzc);
+                            if (at + nzc > kLcCap) qcnt[18] = 1;
+                            else {
+#pragma unroll
+                                for (int q = 0; q < P::G; q++) {
+                                    const uint32_t pm = P::lowmask(1) << (8 * P::BPP * q);
+                                    if ((pff & pm) && !(AT[k] & pm)) Lc[at++] = (uint32_t)(P::G * j + q) | ((uint32_t)(C::RF * C::LPC + tt / GPR) << 16);
+                                }
+                            }
+                        }
+                    }
+                }
             }
         }
         bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
@@ -1079,9 +1122,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                         // lane-local, modulo 2^32 / 2^64: the reduced totals are exact.  (The u16 policy's lanes accumulate
                         // 32 bits inside a 64-bit sum, so there the correction is subtracted after the body.)
+                        if constexpr (C::FULLTAIL) {         // (before the body: its LDS round trip overlaps the row loads)
+                            // the window pixels under the pad bytes of this lane's row-end tail dword leave sy, syy again
+                            const int X = pt.sh + cx;
+                            const uint32_t sft = (uint32_t)((X & (P::G - 1)) * P::BPP);
+                            const uint32_t *rp = reinterpret_cast<const uint32_t *>(W + cy * pt.PW + 4 * (X >> P::LOG2G) + (padoff >= 0 ? padoff : 0));
+                            const uint32_t pb = padoff >= 0 ? (alignb(rp[1], rp[0], sft) & ~C::LASTFF) : 0u;
+                            P::chip_acc(csy, csyy, pb);
+                        }
                         constexpr bool kFold = sizeof(Sum) == 4;
                         if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
-                        acc = eval_round<C, M_FAST, false>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
+                        acc = eval_round<C, M_FAST, false, C::FULLTAIL>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
                         if (!kFold) { acc.sy -= csy; acc.syy -= csyy; }
                         acc.n = 0u - cn; acc.sx = (Sum)0 - csx; acc.sxx = (Sum)0 - csxx;      // + the point's constants, in the finish
                         done = true;
