@@ -209,6 +209,33 @@ def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
             assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), f"ocw{ocw} swapped")
 
 
+@pytest.mark.parametrize("null_frac", [0.10, 0.30])
+@pytest.mark.parametrize("ocw", [30, 40])
+def test_big_chips_with_many_nulls(api, oracle, ocw, null_frac):
+    """Many null pixels on the 61x61 / 81x81 chips: hundreds of entries in the window- and chip-null lists of the sparse
+    corrections (their caps overflow at 30 %: those points fall back to the six-sum body), nulls in the 81-row chip's tail
+    rows (listed since its tail tasks run without derived masks).  u8, u16 and d/dx (u8 through offsets), both directions."""
+    c = synth.make_small(seed=4000 + ocw + int(100 * null_frac), shift=(2, -3), angle_deg=60.0, ocw=ocw, speed=1000.0, h=340, w=350,
+                         dimx=4, dimy=4, noise_dn=2, null_frac=null_frac)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        for mode, path in (("auto", "u8_exact"), ("u16", "u16_scaled")):
+            ctx.set_path(mode)
+            got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+            assert ctx.last_path() == path
+            assert_bits_equal(got, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, ocw), mode)
+            sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
+            assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), mode + " swapped")
+        ctx.set_path("auto")
+        ctx.filter_images(api.CLI_KERNELS[0])
+        f0, f1 = ctx.get_images(H, W)
+        gf = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+        assert ctx.last_path() in ("u8_exact", "u8_offset", "u16_scaled")
+        assert_bits_equal(gf, oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, ocw), "d/dx")
+
+
 def test_edge_cases(api):
     c = synth.make_small(seed=51)
     H, W = c.i0.shape
