@@ -1678,7 +1678,12 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     // speculative 3x3 blocks requested ahead along a straight move: pays on the small chips (cheap evaluations, idle
     // lanes), costs on the big ones (every speculative cell is 60^2..81^2 pixels); measured 1 vs 0: +1 % / -4 %
     static const int look = getenv("MIMC3_U8_LOOKAHEAD") ? atoi(getenv("MIMC3_U8_LOOKAHEAD")) : -1;
-    a.lookahead = look >= 0 ? look : (C::LPC >= 64 ? 0 : 1);
+    // (re-measured on the final build, C2's pair: on the RAW pair the big chips gain too -- smooth NCC surfaces, straight
+    //  climbs: u8 ocw 30 / 40 -1.8 / -1.4 %, f32 ocw 40 -1.3 % -- while the filtered pairs, which are what the u8-through-
+    //  offsets and u16 policies see in the program, lose: d/dx +1.3 / +2 %, Laplacian +4.4 %)
+    //  (the small chips of those two policies as well: Laplacian ocw 7 / 15 -3.2 / -5 %, d/dx ocw 15 -1.3 % without look-ahead)
+    constexpr bool kNoisy = C::P::SRC16 || std::is_same<typename C::P, PxU16>::value;
+    a.lookahead = look >= 0 ? look : (kNoisy ? 0 : 1);
     a.debug_stop = dbg;
     static unsigned long long *d_stats = nullptr;
     static const bool want_stats = getenv("MIMC3_U8_STATS") != nullptr;
