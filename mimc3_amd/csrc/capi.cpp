@@ -63,6 +63,7 @@ struct mimc3_ctx {
     DevBuf fail;                        // [0] count, [1..] points the offset-u8 kernel handed to the u16 kernel
     bool u8o_ok = false;                // integer (shift 0) u16 planes whose local range mostly fits 8 bits: try PxU8o first
     DevBuf hpl0, hpl1;                  // zero-bordered u16 planes of scaled integers (q = value * 2^shift < 4096)
+    DevBuf rt0, rt1;                    // PxU8o: min | max << 16 of every 16x16-pixel tile of hpl0 / hpl1 (valid while u8o_ok)
     bool u16_ok = false;                // the pair is scaled-integer (and not 8-bit): u16 planes are built
     bool hpl_valid = false;             // u16 planes hold the CURRENT pair
     int shift0 = 0, shift1 = 0;
@@ -234,6 +235,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->own_i0.release(); c->own_i1.release();
+    c->rt0.release(); c->rt1.release();
     c->pl0.release(); c->pl1.release(); c->flag.release(); c->ovf.release(); c->fail.release(); c->fpl0.release(); c->fpl1.release(); c->hpl0.release(); c->hpl1.release();
     c->xy.release(); c->puv.release(); c->poff.release(); c->out.release();
     c->qm_io.release(); c->qm_work.release();
@@ -320,6 +322,15 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
                 HIP_TRY(hipMemcpyAsync(t, c->flag.p, sizeof(t), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 c->u8o_ok = 2 * t[0] >= t[1] && 2 * t[2] >= t[3];
+                if (c->u8o_ok) {        // per-tile ranges: the kernel bounds a point's local range from them before it scans pixels
+                    const int Hp = c->H + 2 * pad;
+                    const size_t tb = sizeof(uint32_t) * (size_t)((c->Wp + 15) / 16) * ((Hp + 15) / 16);
+                    HIP_TRY(c->rt0.reserve(tb));
+                    HIP_TRY(c->rt1.reserve(tb));
+                    HIP_TRY(mimc3::launch_range_tiles16(static_cast<const unsigned short *>(c->hpl0.p), Hp, c->Wp, static_cast<uint32_t *>(c->rt0.p), c->stream));
+                    HIP_TRY(mimc3::launch_range_tiles16(static_cast<const unsigned short *>(c->hpl1.p), Hp, c->Wp, static_cast<uint32_t *>(c->rt1.p), c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
             }
         }
     }
@@ -530,7 +541,9 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
                 HIP_TRY(hipMemsetAsync(failb.p, 0, sizeof(int32_t), s));
                 u.fail_count = static_cast<int32_t *>(failb.p);
                 u.fail_list = u.fail_count + 1;
+                if (!getenv("MIMC3_NO_RANGE_TILES")) { u.rt0 = static_cast<const uint32_t *>(c->rt0.p); u.rt1 = static_cast<const uint32_t *>(c->rt1.p); u.rt_tw = (c->Wp + 15) / 16; }
                 e = mimc3::launch_match_u8o(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+                u.rt0 = u.rt1 = nullptr;
                 if (e == hipSuccess) {
                     u.point_count = u.fail_count; u.point_list = u.fail_list;
                     u.fail_count = nullptr; u.fail_list = nullptr;

@@ -57,6 +57,9 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists
     int32_t lds_off_traj;                           // many-pivot configs: recorded climbs of the pivots beyond the first 64
+    // PxU8o: min | max << 16 of the non-null pixels of every 16x16-pixel tile of the two u16 planes (plane coordinates), or null
+    const uint32_t *rt0, *rt1;
+    int32_t rt_tw;                                  // tiles per plane row
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off
@@ -81,6 +84,8 @@ hipError_t launch_match_u16(MatchU8Args a, int max_abs_u, int max_abs_v, int max
 hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 // fraction-of-tiles estimate for the above: out[0] += tiles whose non-null range fits 8 bits, out[1] += tiles with data
 hipError_t launch_range_tiles(const unsigned short *plane, int H, int W, int Wp, int pad, int *d_out2, hipStream_t s);
+// tiles [ceil(Hp/16)][ceil(Wp/16)] of a zero-bordered u16 plane (Hp rows): min | max << 16 over the non-null pixels (0xffff | 0 if none)
+hipError_t launch_range_tiles16(const unsigned short *plane, int Hp, int Wp, uint32_t *tiles, hipStream_t s);
 // same kernel family on zero-bordered f32 planes (any f32 imagery; small chips only)
 hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp, int pad, hipStream_t s);
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v);

@@ -595,7 +595,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // ([11..14]: PxU8o only -- min/max of the non-null window and chip pixels)
     for (int i = tid; i < 6 * kSumBatch; i += NT) sums[i] = 0;             // parking slots of the atomically parked sums
     // [16] window-null list length, [17] chip-null list length, [18] a list overflowed (SPARSE configs)
-    if (tid < 32) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14) ? -1 : 0);
+    // ([19..22]: PxU8o only -- the same from the planes' 16x16-pixel tile ranges: a cheap bound tried first)
+    if (tid < 32) qcnt[tid] = (tid == 5 || tid == 7 || tid == 11 || tid == 13 || tid == 19 || tid == 21) ? (1 << 20) : ((tid == 6 || tid == 8 || tid == 12 || tid == 14 || tid == 20 || tid == 22) ? -1 : 0);
     unsigned char *CH = smem + p.lds_off_chip;                             // SPARSE: chip copy [CW][CPITCH]
     uint32_t *Lw = reinterpret_cast<uint32_t *>(smem + p.lds_off_lw);      // SPARSE: null pixels of the window (x | y << 16)
     uint32_t *Lc = reinterpret_cast<uint32_t *>(smem + p.lds_off_lc);      // SPARSE: null pixels of the chip's row-task rows
@@ -637,7 +638,47 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const uint2 *gbase16 = reinterpret_cast<const uint2 *>(win_pl + ((size_t)wv0 * Wp + (wu0 - pt.sh)) * 2);
         const int gpitch16 = Wp >> 2;
         (void)gbase16; (void)gpitch16;
+        bool have_k = false;                                  // PxU8o: offsets found from the tile ranges (the exact scan is skipped)
         if constexpr (P::SRC16) {
+            if (p.rt0) {
+                // A bound first: the ranges of the 16x16-pixel tiles the window / the chip touch (a superset of their pixels).
+                // If both fit 8 bits, offsets from these bounds are as good as the exact ones -- the finish rebuilds the true
+                // integer sums from ANY offsets that keep every pixel inside a byte -- and the full scan below is not needed.
+                const uint32_t *wrt = p.swap ? p.rt0 : p.rt1, *crt = p.swap ? p.rt1 : p.rt0;
+                int tmn = 0xffff, tmx = 0, cmn2 = 0xffff, cmx2 = 0;
+                {
+                    const int tx0 = wu0 >> 4, ty0 = wv0 >> 4, ntx = ((wu0 + wcols - 1) >> 4) - tx0 + 1, nty = ((wv0 + wrows - 1) >> 4) - ty0 + 1;
+                    for (int i = tid; i < ntx * nty; i += NT) {
+                        const int iy = i / ntx, ix = i - iy * ntx;
+                        const uint32_t t = wrt[(ty0 + iy) * p.rt_tw + tx0 + ix];
+                        tmn = min(tmn, (int)(t & 0xffffu)); tmx = max(tmx, (int)(t >> 16));
+                    }
+                    const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;
+                    const int cx0 = cu0 >> 4, cy0 = cv0 >> 4, ncx = ((cu0 + CW - 1) >> 4) - cx0 + 1, ncy = ((cv0 + CW - 1) >> 4) - cy0 + 1;
+                    for (int i = tid; i < ncx * ncy; i += NT) {
+                        const int iy = i / ncx, ix = i - iy * ncx;
+                        const uint32_t t = crt[(cy0 + iy) * p.rt_tw + cx0 + ix];
+                        cmn2 = min(cmn2, (int)(t & 0xffffu)); cmx2 = max(cmx2, (int)(t >> 16));
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    tmn = min(tmn, __shfl_xor(tmn, o, 64)); tmx = max(tmx, __shfl_xor(tmx, o, 64));
+                    cmn2 = min(cmn2, __shfl_xor(cmn2, o, 64)); cmx2 = max(cmx2, __shfl_xor(cmx2, o, 64));
+                }
+                if (NW > 1) {
+                    if (lane == 0) { atomicMin(&qcnt[19], tmn); atomicMax(&qcnt[20], tmx); atomicMin(&qcnt[21], cmn2); atomicMax(&qcnt[22], cmx2); }
+                    __syncthreads();
+                    tmn = qcnt[19]; tmx = qcnt[20]; cmn2 = qcnt[21]; cmx2 = qcnt[22];
+                }
+                if ((tmx == 0 || tmx - tmn <= 254) && (cmx2 == 0 || cmx2 - cmn2 <= 254)) {
+                    kb = tmx == 0 ? 0 : tmn - 1;
+                    ka = cmx2 == 0 ? 0 : cmn2 - 1;
+                    have_k = true;
+                }
+            }
+        }
+        if constexpr (P::SRC16) if (!have_k) {
             // pass 1: local range of the window and of the chip; a point that does not fit 8 bits goes to the u16 kernel
             // (both scans fetch eight values before they use any: the loops are chains of global loads otherwise)
             int mn = 1 << 20, mx = -1;
@@ -1799,6 +1840,37 @@ __global__ __launch_bounds__(256) void range_tiles(const unsigned short *__restr
         for (int w = 1; w < 4; w++) { mn = min(mn, smn[w]); mx = max(mx, smx[w]); }
         if (mx >= mn) { atomicAdd(&out2[1], 1); if (mx - mn <= 254) atomicAdd(&out2[0], 1); }
     }
+}
+
+// ---- per-tile ranges of a u16 plane: 16 lanes = the 16 rows of one 16x16-pixel tile -------------------------------------
+__global__ __launch_bounds__(256) void range_tiles16(const unsigned short *__restrict__ plane, int Hp, int Wp, int tw, int ntiles, uint32_t *__restrict__ tiles)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int tile = gid >> 4, r = gid & 15;
+    int mn = 0xffff, mx = 0;
+    if (tile < ntiles) {
+        const int ty = tile / tw, tx = tile - ty * tw;
+        const int row = ty * 16 + r, col0 = tx * 16;
+        if (row < Hp) {
+            const unsigned short *q = plane + (size_t)row * Wp + col0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int v = (col0 + c < Wp) ? q[c] : 0;
+                mx = max(mx, v);
+                mn = v ? min(mn, v) : mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 16)); mx = max(mx, __shfl_xor(mx, o, 16)); }
+    if (tile < ntiles && r == 0) tiles[tile] = (uint32_t)mn | ((uint32_t)mx << 16);
+}
+
+hipError_t launch_range_tiles16(const unsigned short *plane, int Hp, int Wp, uint32_t *tiles, hipStream_t s)
+{
+    const int tw = (Wp + 15) / 16, th = (Hp + 15) / 16, nt = tw * th;
+    hipLaunchKernelGGL(range_tiles16, dim3((unsigned)((nt * 16 + 255) / 256)), dim3(256), 0, s, plane, Hp, Wp, tw, nt, tiles);
+    return hipGetLastError();
 }
 
 hipError_t launch_range_tiles(const unsigned short *plane, int H, int W, int Wp, int pad, int *d_out2, hipStream_t s)
