@@ -236,6 +236,31 @@ def test_big_chips_with_many_nulls(api, oracle, ocw, null_frac):
         assert_bits_equal(gf, oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, ocw), "d/dx")
 
 
+@pytest.mark.parametrize("ocw", [7, 15, 30, 40])
+def test_offsets_from_tile_ranges_or_from_the_full_scan(api, oracle, ocw, monkeypatch):
+    """u8 through per-point offsets (gradient of an 8-bit pair): the offsets come from the planes' 16x16-pixel tile ranges where
+    that bound fits a byte, from the full scan of the point's pixels where it does not, and the point goes to the u16 kernel
+    where even the exact range does not fit.  Any valid offsets give the same exact sums: with the tile bound switched off the
+    result must not change, and both equal the reference.  Noise 12 DN spreads the local ranges around the 8-bit limit."""
+    c = synth.make_small(seed=5100 + ocw, shift=(1, -2), angle_deg=25.0, ocw=ocw, speed=900.0, h=330, w=350, dimx=5, dimy=4,
+                         noise_dn=12, null_frac=0.02)
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        ctx.filter_images(api.CLI_KERNELS[1])
+        f0, f1 = ctx.get_images(H, W)
+        want = oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, ocw)
+        a = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+        path = ctx.last_path()
+        monkeypatch.setenv("MIMC3_NO_RANGE_TILES", "1")
+        b = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+        monkeypatch.delenv("MIMC3_NO_RANGE_TILES")
+    assert path in ("u8_offset", "u16_scaled", "u8_exact")
+    assert_bits_equal(a, want, "tile bound")
+    assert_bits_equal(b, want, "full scan")
+
+
 def test_edge_cases(api):
     c = synth.make_small(seed=51)
     H, W = c.i0.shape
