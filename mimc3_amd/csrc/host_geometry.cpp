@@ -4,6 +4,7 @@
 // Both are O(N) integer/trig bookkeeping whose results must equal the reference's libm-based
 // float/double mix bit for bit, so they run on the host with the same libm.
 // Every implicit C promotion of the reference is spelled out here as an explicit cast.
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -18,6 +19,7 @@ namespace {
 struct Corridor {
     float incr_u, incr_v, norm_incr;
     double length;
+    explicit Corridor(const mimc3::CorridorPOD &c) : incr_u(c.incr_u), incr_v(c.incr_v), norm_incr(c.norm_incr), length(c.length) {}
     Corridor(double vx, double vy, float dt, float mpp, float aw_sf, float aw_cre)
     {
         const float theta = (float)std::atan2(vy, vx);
@@ -66,27 +68,46 @@ struct Corridor {
 
 }  // namespace
 
-extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre,
-                                  int32_t ocw, int32_t H, int32_t W, int64_t *piv_off, int32_t *piv_uv,
-                                  int64_t cap, int64_t *total)
+namespace {
+// points are independent: the passes run on a few host threads
+template <class Body> void run_threads(int32_t N, Body &&body)
 {
-    if (!xyuvav || !piv_off || !total || N <= 0 || ocw < 1 || H <= 0 || W <= 0)
-        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_uv_pivot: bad argument");
-    // points are independent: both passes (count, fill) run on a few host threads; the prefix sum stays serial
-    const auto run = [&](auto &&body) {
-        unsigned nt = N >= 20000 ? std::thread::hardware_concurrency() : 1;
-        nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
-        if (nt == 1) { body(0, N); return; }
-        std::vector<std::thread> th;
-        const int32_t step = (N + (int32_t)nt - 1) / (int32_t)nt;
-        for (int32_t b = 0; b < N; b += step) th.emplace_back(body, b, b + step < N ? b + step : N);
-        for (auto &t : th) t.join();
-    };
-    run([&](int32_t b, int32_t e) {
+    unsigned nt = N >= 20000 ? std::thread::hardware_concurrency() : 1;
+    nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+    if (nt == 1) { body(0, N); return; }
+    std::vector<std::thread> th;
+    const int32_t step = (N + (int32_t)nt - 1) / (int32_t)nt;
+    for (int32_t b = 0; b < N; b += step) th.emplace_back(body, b, b + step < N ? b + step : N);
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
+void mimc3::pivot_corridors(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre, CorridorPOD *cor)
+{
+    run_threads(N, [&](int32_t b, int32_t e) {
         for (int32_t g = b; g < e; ++g) {
             const double *r = xyuvav + 6 * (size_t)g;
             const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
-            piv_off[g + 1] = c.count(r[2], r[3], ocw, H, W);
+            cor[g] = CorridorPOD{c.incr_u, c.incr_v, c.norm_incr, c.length};
+        }
+    });
+}
+
+// both entry points: corridors from `cor` when given, else computed per point (twice: count and fill)
+static int get_uv_pivot_impl(const mimc3::CorridorPOD *cor, const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre,
+                             int32_t ocw, int32_t H, int32_t W, int64_t *piv_off, int32_t *piv_uv, int64_t cap, int64_t *total,
+                             int32_t *ext = nullptr)
+{
+    if (!xyuvav || !piv_off || !total || N <= 0 || ocw < 1 || H <= 0 || W <= 0)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_uv_pivot: bad argument");
+    const auto corridor = [&](int32_t g) {
+        const double *r = xyuvav + 6 * (size_t)g;
+        return cor ? Corridor(cor[g]) : Corridor(r[4], r[5], dt, mpp, aw_sf, aw_cre);
+    };
+    run_threads(N, [&](int32_t b, int32_t e) {
+        for (int32_t g = b; g < e; ++g) {
+            const double *r = xyuvav + 6 * (size_t)g;
+            piv_off[g + 1] = corridor(g).count(r[2], r[3], ocw, H, W);
         }
     });
     int64_t tot = 0;
@@ -102,14 +123,36 @@ extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, flo
     if (empty) return mimc3::fail(MIMC3_EBOUNDS, "mimc3_get_uv_pivot: a grid point has zero pivots (too close to the image edge)");
     if (!piv_uv) return 0;
     if (cap < tot) return mimc3::fail(MIMC3_ECAP, "mimc3_get_uv_pivot: pivot capacity too small");
-    run([&](int32_t b, int32_t e) {
+    std::atomic<int32_t> mn{0}, mu{0}, mv{0};
+    run_threads(N, [&](int32_t b, int32_t e) {
+        int32_t ln = 0, lu = 0, lv = 0;
         for (int32_t g = b; g < e; ++g) {
-            const double *r = xyuvav + 6 * (size_t)g;
-            const Corridor c(r[4], r[5], dt, mpp, aw_sf, aw_cre);
-            c.fill((int32_t)(piv_off[g + 1] - piv_off[g]), piv_uv + 2 * piv_off[g]);
+            const int32_t n = (int32_t)(piv_off[g + 1] - piv_off[g]);
+            int32_t *uv = piv_uv + 2 * piv_off[g];
+            corridor(g).fill(n, uv);
+            ln = n > ln ? n : ln;                              // (only the LAST pivot sizes the window, :863-864)
+            const int32_t au = std::abs(uv[2 * (n - 1)]), av = std::abs(uv[2 * (n - 1) + 1]);
+            lu = au > lu ? au : lu; lv = av > lv ? av : lv;
         }
+        auto amax = [](std::atomic<int32_t> &a, int32_t v) { int32_t cur = a.load(); while (v > cur && !a.compare_exchange_weak(cur, v)) {} };
+        amax(mn, ln); amax(mu, lu); amax(mv, lv);
     });
+    if (ext) { ext[0] = mn.load(); ext[1] = mu.load(); ext[2] = mv.load(); }
     return 0;
+}
+
+extern "C" int mimc3_get_uv_pivot(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre,
+                                  int32_t ocw, int32_t H, int32_t W, int64_t *piv_off, int32_t *piv_uv,
+                                  int64_t cap, int64_t *total)
+{
+    return get_uv_pivot_impl(nullptr, xyuvav, N, dt, mpp, aw_sf, aw_cre, ocw, H, W, piv_off, piv_uv, cap, total);
+}
+
+int mimc3::get_uv_pivot_cor(const CorridorPOD *cor, const double *xyuvav, int32_t N, int32_t ocw, int32_t H, int32_t W, int64_t *piv_off,
+                            int32_t *piv_uv, int64_t cap, int64_t *total, int32_t *ext)
+{
+    if (!cor) return mimc3::fail(MIMC3_EINVAL, "get_uv_pivot_cor: no corridors");
+    return get_uv_pivot_impl(cor, xyuvav, N, 0.0f, 1.0f, 0.0f, 0.0f, ocw, H, W, piv_off, piv_uv, cap, total, ext);
 }
 
 extern "C" int mimc3_pivot_extent(const int32_t *piv_uv, const int64_t *piv_off, int32_t N, int32_t *max_npiv,

@@ -158,6 +158,13 @@ int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, flo
     // the four chip sizes are independent: one host thread each (every one of them fans out again inside mimc3_get_uv_pivot)
     int rcs[4] = {0, 0, 0, 0};
     std::string errs[4];
+    // the corridor of a point (its atan2 / sin / cos) is the same for all four chip sizes: once per point
+    static const bool tm = getenv("MIMC3_VMAP_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](int c, const char *w) { if (tm) fprintf(stderr, "[mimc3 piv %d] %-10s at %.2f ms\n", c, w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
+    std::vector<mimc3::CorridorPOD> cor((size_t)ns);
+    mimc3::pivot_corridors(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, cor.data());
+    lap(-1, "corridors");
     // device copies: forward and negated (:272-279) pivots + offsets, on a stream of this thread's own
     auto upload = [&](int c) -> int {
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -179,12 +186,16 @@ int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, flo
     };
     auto one = [&](int c) {
         hp[c].off.resize((size_t)ns + 1);
-        int rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
+        int32_t ext[3] = {0, 0, 0};
+        int rc = mimc3::get_uv_pivot_cor(cor.data(), xs, ns, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
+        lap(c, "count");
         if (!rc) rc = mimc3_ctx_host_workspace(ctx, c, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), &hp[c].uv);   // pinned, kept across calls
-        if (!rc) rc = mimc3_get_uv_pivot(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, p->vec_ocw[c], H, W, hp[c].off.data(),
-                                         static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total);
-        if (!rc) rc = mimc3_pivot_extent(static_cast<int32_t *>(hp[c].uv), hp[c].off.data(), ns, &hp[c].mn, &hp[c].mu, &hp[c].mv);
+        if (!rc) rc = mimc3::get_uv_pivot_cor(cor.data(), xs, ns, p->vec_ocw[c], H, W, hp[c].off.data(),
+                                              static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total, ext);
+        if (!rc) { hp[c].mn = ext[0]; hp[c].mu = ext[1]; hp[c].mv = ext[2]; }
+        lap(c, "fill");
         if (!rc) rc = upload(c);
+        lap(c, "upload");
         if (rc) { errs[c] = mimc3_last_error(); rcs[c] = rc; }          // the message is thread-local: carry it over
     };
     if (ns >= 20000) {
