@@ -198,33 +198,22 @@ def get_ruv_neighbor(xyuvav, dimx, dimy, meter_per_spacing, radius, cap=4096):
     return np.ascontiguousarray(ruv[:nn.value])
 
 
-class _Pinned:
-    def __init__(self, nbytes):
-        self.p = _lib.mimc3_host_alloc(nbytes)
-        if not self.p:
-            raise MemoryError("mimc3_host_alloc failed")
-        self.buf = (C.c_char * nbytes).from_address(self.p)
-
-    def __del__(self):
-        if getattr(self, "p", None):
-            _lib.mimc3_host_free(self.p)
-            self.p = None
-
-
 def pinned_empty(shape, dtype):
-    """numpy array in pinned host memory (mimc3_host_alloc): host<->device copies of it need no staging."""
-    dt = np.dtype(dtype)
-    n = int(np.prod(shape)) * dt.itemsize
-    pin = _Pinned(max(n, 1))
-    a = np.frombuffer(pin.buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
-    a.flags.writeable = True
-    _PIN_KEEP[id(a)] = pin
+    """numpy array in pinned host memory (mimc3_host_alloc): host<->device copies of it need no staging.
+    The block lives as long as ANY view of it: numpy keeps the ctypes buffer object as the base of the array and of every
+    slice taken from it, and the block is freed by a finalizer on that buffer object (not on the first array)."""
     import weakref
-    weakref.finalize(a, _PIN_KEEP.pop, id(a), None)
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dt.itemsize, 1)
+    p = _lib.mimc3_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("mimc3_host_alloc failed")
+    buf = (C.c_char * nbytes).from_address(p)
+    weakref.finalize(buf, _lib.mimc3_host_free, p)
+    a = np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+    a.flags.writeable = True
     return a
-
-
-_PIN_KEEP = {}
 
 
 def point_cost(piv_off, ocw, cost=None):

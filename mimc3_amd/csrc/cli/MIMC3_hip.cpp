@@ -185,15 +185,23 @@ int main(int argc, char *argv[])
         if (ctx_rc) ctx_err = mimc3_last_error();
     });
     auto cleanup = [&]() { if (ctx) mimc3_ctx_destroy(ctx); if (mg) mimc3_mgpu_destroy(mg); ctx = nullptr; mg = nullptr; };
+    // Every exit once the device context may exist goes through here: flush, then _exit.  Returning from main() would run
+    // the static destructors of the HIP runtime (and of RCCL with MIMC3_HIP_DEVICES) with contexts, streams and communicators
+    // still alive -- on some RCCL versions that hangs or aborts, turning a clean error code into a signal.
+    auto leave = [&](int code) -> int {
+        fflush(nullptr);
+        if (getenv("MIMC3_CLI_TEARDOWN")) { cleanup(); return code; }     // (leak checkers)
+        _exit(code);
+    };
     RawImage i0, i1;
     lap("xyuvav read");
     const bool tiff_ok = load_tiff(argv[1], i0) && load_tiff(argv[2], i1);
     lap("TIFF decode");
     ctx_thread.join();
     lap("device context (rest of)");
-    if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); cleanup(); return 2; }
-    if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); cleanup(); return 2; }
-    if (ctx_rc) { fprintf(stderr, "%s\n", ctx_err.c_str()); return 3; }
+    if (!tiff_ok) { fprintf(stderr, "cannot read the TIFF images\n"); return leave(2); }
+    if (i0.H != i1.H || i0.W != i1.W) { fprintf(stderr, "the two images differ in size\n"); return leave(2); }
+    if (ctx_rc) { fprintf(stderr, "%s\n", ctx_err.c_str()); return leave(3); }
     const int32_t H = i0.H, W = i0.W;
     int rc;
     if (i0.bpp == 1 && i1.bpp == 1)
@@ -210,7 +218,7 @@ int main(int argc, char *argv[])
         widen(i0, f0); widen(i1, f1);
         rc = mg ? mimc3_mgpu_set_images(mg, f0.data(), f1.data(), H, W) : mimc3_ctx_set_images(ctx, f0.data(), f1.data(), H, W);
     }
-    if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); cleanup(); return 3; }
+    if (rc) { fprintf(stderr, "%s\n", mimc3_last_error()); return leave(3); }
     lap("pair upload");
 
     std::vector<float> vx(N), vy(N), ex(N), ey(N), qual(N);
@@ -220,8 +228,7 @@ int main(int argc, char *argv[])
             : mimc3_vmap(ctx, xy.data(), N, dt, &p, vx.data(), vy.data(), ex.data(), ey.data(), qual.data(), flag.data(), &r);
     if (rc) {
         fprintf(stderr, "%s\n", mimc3_last_error());
-        cleanup();
-        return 3;
+        return leave(3);
     }
     lap("vmap (data path)");
     if (mg) printf("grid points sharded over %d GPU(s), work imbalance %.1f %%\n", (int)mimc3_mgpu_ndev(mg), 100.0 * mimc3_mgpu_last_imbalance(mg));
@@ -233,7 +240,7 @@ int main(int argc, char *argv[])
         printf("Generating dummy vmap file.\n");
         FILE *f = fopen(f_tar.c_str(), "ab");
         if (f) fclose(f);
-        return -1;
+        return leave(-1);
     }
     printf("Measured offset: [%d, %d] pixels (i1-i0)\n", r.offset_cp[0], r.offset_cp[1]);
 
@@ -252,10 +259,8 @@ int main(int argc, char *argv[])
                 ver, argv[1], argv[2], r.offset_cp[0], r.offset_cp[1], r.cp_subint[0], r.cp_subint[1]);
         ok = fclose(fm) == 0 && ok;
     } else ok = false;
-    if (!ok) { fprintf(stderr, "could not write the outputs under %s\n", argv[4]); return 4; }
+    if (!ok) { fprintf(stderr, "could not write the outputs under %s\n", argv[4]); return leave(4); }
     lap("outputs written");
     printf("Processing completed\n");
-    fflush(nullptr);
-    if (getenv("MIMC3_CLI_TEARDOWN")) { cleanup(); return 0; }     // (leak checkers)
-    _exit(0);
+    return leave(0);
 }

@@ -143,9 +143,14 @@ extern "C" int mimc3_mgpu_create(const int32_t *devices, int32_t ndev, mimc3_mgp
 {
     if (!out || !devices || ndev <= 0 || ndev > 64) return mimc3::fail(MIMC3_EINVAL, "mimc3_mgpu_create: bad argument");
     *out = nullptr;
-    for (int32_t a = 0; a < ndev; a++)
-        for (int32_t b = a + 1; b < ndev; b++)
-            if (devices[a] == devices[b]) return mimc3::fail(MIMC3_EINVAL, "mimc3_mgpu_create: a device is listed twice (one rank per GPU)");
+    // One rank per GPU.  TEST-ONLY switch: MIMC3_MGPU_ALLOW_REPEAT=1 lets a device be listed several times, so that a
+    // one-GPU box can run N ranks as N contexts of the same device (together with a stand-in communicator selected through
+    // MIMC3_RCCL_LIB, tests/fake_rccl.c -- RCCL itself refuses such a device list); it measures nothing and is not a product mode.
+    const char *rep = getenv("MIMC3_MGPU_ALLOW_REPEAT");
+    if (!(rep && rep[0] == '1'))
+        for (int32_t a = 0; a < ndev; a++)
+            for (int32_t b = a + 1; b < ndev; b++)
+                if (devices[a] == devices[b]) return mimc3::fail(MIMC3_EINVAL, "mimc3_mgpu_create: a device is listed twice (one rank per GPU)");
     Rccl &r = rccl();
     if (!r.err.empty()) return mimc3::fail(MIMC3_ENODEV, "mimc3_mgpu_create: " + r.err);
     mimc3_mgpu *mg = new mimc3_mgpu();
@@ -192,7 +197,15 @@ int per_device(mimc3_mgpu *mg, F fn)
     if (rc[0]) err[0] = mimc3_last_error();
     for (auto &t : th) t.join();
     for (size_t k = 0; k < n; k++)
-        if (rc[k]) return mimc3::fail(rc[k], "rank " + std::to_string(k) + " (device " + std::to_string(mg->dev[k]) + "): " + err[k]);
+        if (rc[k]) {
+            // the other ranks may hold enqueued work on their contexts' cached buffers: drain every stream before the caller
+            // sees the failure (and possibly destroys or reuses the contexts)
+            for (size_t j = 0; j < n; j++) {
+                (void)hipSetDevice(mg->dev[j]);
+                (void)hipStreamSynchronize(static_cast<hipStream_t>(mimc3_ctx_stream(mg->ctx[j])));
+            }
+            return mimc3::fail(rc[k], "rank " + std::to_string(k) + " (device " + std::to_string(mg->dev[k]) + "): " + err[k]);
+        }
     return 0;
 }
 
@@ -204,7 +217,16 @@ int all_gather(mimc3_mgpu *mg, const std::vector<const float *> &d_send, const s
     for (size_t k = 0; k < mg->ctx.size(); k++) {
         HIP_TRY(hipSetDevice(mg->dev[k]));
         int e = r.AllGather(d_send[k], d_recv[k], count, kNcclFloat, mg->comm[k], static_cast<hipStream_t>(mimc3_ctx_stream(mg->ctx[k])));
-        if (e != 0) { (void)r.GroupEnd(); return nccl_fail(e, "ncclAllGather"); }
+        if (e != 0) {
+            // close the group (the calls already posted are abandoned with it), then drain the streams: nothing of the
+            // half-issued collective may still be running when the caller reuses the buffers
+            (void)r.GroupEnd();
+            for (size_t j = 0; j < mg->ctx.size(); j++) {
+                (void)hipSetDevice(mg->dev[j]);
+                (void)hipStreamSynchronize(static_cast<hipStream_t>(mimc3_ctx_stream(mg->ctx[j])));
+            }
+            return nccl_fail(e, "ncclAllGather");
+        }
     }
     NCCL_TRY(r.GroupEnd());
     return 0;

@@ -232,7 +232,10 @@ int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_
 int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t off[2], HostPivots hp[4], const mimc3_vmap_params *p,
                     float *d_dp, size_t pass_stride)
 {
-    if (pass_stride < (size_t)ns) pass_stride = (size_t)ns;   // points per pass slot of d_dp (a multi-GPU driver pads its blocks)
+    // points per pass slot of d_dp (a multi-GPU driver pads its blocks); 0 = ns.  A stride below ns would make the passes write
+    // past the caller's [32][pass_stride][3] buffer: refused, not silently raised
+    if (pass_stride == 0) pass_stride = (size_t)ns;
+    if (pass_stride < (size_t)ns) return mimc3::fail(MIMC3_EINVAL, "vmap_run_passes: pass_stride is smaller than the number of points");
     int32_t H = 0, W = 0;
     RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
     StageClock clk;
@@ -338,6 +341,7 @@ extern "C" int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_
                                         const mimc3_vmap_result *res, float *d_dp, int64_t pass_stride)
 {
     if (!ctx || !xs || !p || !res || !d_dp || n < 1 || res->cp_status < 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_passes_points: bad argument");
+    if (pass_stride > 0 && pass_stride < n) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_passes_points: 0 < pass_stride < n (d_dp is [32][pass_stride][3]; 0 means n)");
     int32_t H = 0, W = 0;
     RC_TRY(mimc3_ctx_image_size(ctx, &H, &W));
     mimc3::HostPivots hp[4];

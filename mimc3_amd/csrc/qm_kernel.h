@@ -7,7 +7,8 @@ namespace mimc3 {
 
 constexpr int kQmThreads = 128;
 constexpr int kQmFlagWords = 16;
-enum { kQmAny = 0, kQmDone = 1, kQmSweeps = 2, kQmSkipped = 3 };
+enum { kQmAny = 0, kQmDone = 1, kQmSweeps = 2, kQmSkipped = 3, kQmTicket = 4 };
+constexpr int kQmLaunchesPerSweep = 2;
 
 struct QmArgs {
     int32_t dimy, dimx, N;
@@ -29,7 +30,7 @@ struct QmArgs {
 };
 
 int64_t qm_workspace_bytes(int32_t n, int32_t max_sweeps);
-// Enqueues init + max_sweeps x (sweep, commit, compare, decide); flags[kQmSweeps] holds the
+// Enqueues init + max_sweeps x (sweep, finish_sweep); flags[kQmSweeps] holds the
 // reference's NOI at exit once the stream has drained.
 hipError_t launch_qm(QmArgs a, void *work, hipStream_t stream);
 // word offset of the flags block inside the workspace (for reading sweeps_done back)

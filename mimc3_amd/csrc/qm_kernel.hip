@@ -13,11 +13,10 @@
 // tie.  Outputs are cluster ids and copied f32 cluster means, so they are
 // otherwise bit-identical.
 //
-// Per sweep (all device side, early-out on a device flag, no host sync):
-//   qm_sweep   : fit + nearest candidate per masked point, mark neighbours for the next sweep
-//   qm_commit  : Jacobi commit of the buffers, clear the mask buffer that becomes "next"
-//   qm_compare : next mask vs every earlier mask of the stack ("fluctuation", :2237-2261)
-//   qm_decide  : one thread: termination logic of the while loop (:2077, :2263-2286)
+// Per sweep, TWO launches (all device side, early-out on a device flag, no host sync):
+//   qm_sweep        : fit + nearest candidate per masked point, mark neighbours for the next sweep
+//   qm_finish_sweep : Jacobi commit of the buffers; next mask vs every earlier mask of the stack ("fluctuation",
+//                     :2237-2261); the block that retires last runs the termination logic of the while loop (:2077, :2263-2286)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qm_kernel.h"
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(kQmThreads) void qm_init(QmArgs a)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         a.flags[kQmAny] = 0; a.flags[kQmDone] = 0; a.flags[kQmSweeps] = 0;
-        a.flags[kQmSkipped] = 0;
+        a.flags[kQmSkipped] = 0; a.flags[kQmTicket] = 0;
     }
     if (i < a.max_sweeps + 2) a.diff[i] = 0;
     if (i >= a.N) return;
@@ -165,39 +164,49 @@ __global__ __launch_bounds__(kQmThreads) void qm_sweep(QmArgs a, int sweep)
     }
 }
 
-__global__ __launch_bounds__(kQmThreads) void qm_commit(QmArgs a, int sweep)
+// Second (and last) launch of a sweep: the Jacobi commit (:2218-2233), the comparison of the next mask with every earlier mask
+// of the stack ("fluctuation", :2237-2261) and -- by the block that retires last -- the termination logic of the while loop
+// (:2077, :2263-2286).  The commit and the compare are per grid point; the decision needs every block's compare result:
+// waves OR their mismatch bits (bit s = "the next mask differs from mask s somewhere in this wave") into packed words with
+// device-scope atomics, a ticket counts retired blocks, and the last one reads the words back with atomic loads.
+__global__ __launch_bounds__(kQmThreads) void qm_finish_sweep(QmArgs a, int sweep)
 {
     if (a.flags[kQmDone]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.N) return;
-    const int b = a.bid[i];
-    if (b >= 0) {                                                        // :2222-2231
-        a.dx[i] = a.bx[i]; a.dy[i] = a.by[i]; a.dpf[i] = b;
-        const float nanv = __builtin_nanf("");
-        a.bx[i] = nanv; a.by[i] = nanv; a.bid[i] = -1;
+    const bool in = i < a.N;
+    if (in) {
+        const int b = a.bid[i];
+        if (b >= 0) {                                                    // :2222-2231
+            a.dx[i] = a.bx[i]; a.dy[i] = a.by[i]; a.dpf[i] = b;
+            const float nanv = __builtin_nanf("");
+            a.bx[i] = nanv; a.by[i] = nanv; a.bid[i] = -1;
+        }
+        a.mask[(sweep - 1) & 1][i] = 0;   // was "current"; becomes "next" of sweep+1
     }
-    a.mask[(sweep - 1) & 1][i] = 0;   // was "current"; becomes "next" of sweep+1
-}
-
-__global__ __launch_bounds__(kQmThreads) void qm_compare(QmArgs a, int sweep)
-{
-    if (a.flags[kQmDone]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.N) return;
-    const unsigned char m = a.mask[sweep & 1][i];
-    for (int s = 0; s < sweep; s++)
-        if (a.stack[(size_t)s * a.N + i] != m) a.diff[s] = 1;
-    a.stack[(size_t)sweep * a.N + i] = m;                                // :2272-2284 (harmless if we stop)
-}
-
-__global__ void qm_decide(QmArgs a, int sweep)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (a.flags[kQmDone]) return;
+    const unsigned char m = in ? a.mask[sweep & 1][i] : (unsigned char)0;
+    uint32_t word = 0u;                                                  // wave-uniform: mismatch bits of stack entries 32w .. 32w+31
+    for (int s = 0; s < sweep; s++) {
+        const bool ne = in && a.stack[(size_t)s * a.N + i] != m;
+        if (__ballot(ne) != 0ull) word |= 1u << (s & 31);
+        if ((s & 31) == 31 || s == sweep - 1) {
+            if ((threadIdx.x & 63) == 0 && word) atomicOr(reinterpret_cast<unsigned int *>(&a.diff[s >> 5]), word);
+            word = 0u;
+        }
+    }
+    if (in) a.stack[(size_t)sweep * a.N + i] = m;                        // :2272-2284 (harmless if we stop)
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&a.flags[kQmTicket], 1) != (int)gridDim.x - 1) return;
+    // ---- the last block: qm_decide
+    a.flags[kQmTicket] = 0;
     bool fluct = false;
-    for (int s = sweep - 1; s >= 0; s--) {
-        if (a.diff[s] == 0) fluct = true;
-        a.diff[s] = 0;
+    for (int w = 0; w <= (sweep - 1) >> 5; w++) {
+        const uint32_t have = __hip_atomic_load(reinterpret_cast<unsigned int *>(&a.diff[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nbits = (sweep - 32 * w) < 32 ? (sweep - 32 * w) : 32;
+        const uint32_t all = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
+        if ((have & all) != all) fluct = true;                           // some earlier mask equals the next one everywhere
+        a.diff[w] = 0;
     }
     if (fluct) { a.flags[kQmSweeps] = sweep - 1; a.flags[kQmDone] = 1; return; }   // :2263-2268 (NOI--)
     a.flags[kQmSweeps] = sweep;
@@ -234,9 +243,7 @@ hipError_t launch_qm(QmArgs a, void *work, hipStream_t stream)
     hipLaunchKernelGGL(qm_init, dim3(nbi), dim3(kQmThreads), 0, stream, a);
     for (int s = 1; s <= a.max_sweeps; s++) {
         hipLaunchKernelGGL(qm_sweep, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
-        hipLaunchKernelGGL(qm_commit, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
-        hipLaunchKernelGGL(qm_compare, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
-        hipLaunchKernelGGL(qm_decide, dim3(1), dim3(64), 0, stream, a, s);
+        hipLaunchKernelGGL(qm_finish_sweep, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
     }
     return hipGetLastError();
 }

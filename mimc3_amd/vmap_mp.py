@@ -26,7 +26,7 @@ def vmap_sharded(ctx, xyuvav, dt, rank, world, device, **kw):
     if rank == 0:
         try:
             r, flag = ctx.vmap_cp(xy, dt, **kw)
-        except api.Mimc3Error as e:
+        except Exception as e:     # ANY failure must reach the agreement step below, or the peers wait in it for ever
             err = e
     if not shard.all_ok(err is None, device):
         raise err if err is not None else RuntimeError("vmap_sharded: the control-point stage failed on rank 0")
@@ -53,9 +53,12 @@ def vmap_sharded(ctx, xyuvav, dt, rank, world, device, **kw):
         order, start, per, _ = shard.balanced_shares(cost, world)
         mine = order[start[rank]:start[rank + 1]]
         local = torch.full((32, per, 3), float("nan"), dtype=torch.float32, device=device)     # padded to the largest share
+        # the fill above is enqueued on torch's stream, the passes below write the same buffer on the library's own
+        # (non-blocking) stream: order them, or a late fill overwrites candidates with NaN
+        torch.cuda.current_stream(device).synchronize()
         if len(mine):
             ctx.vmap_passes_points(np.ascontiguousarray(xy[mine]), dt, r, local.data_ptr(), per, **kw)
-    except api.Mimc3Error as e:
+    except Exception as e:         # (torch OOM, ValueError, ...: not only Mimc3Error -- every rank must reach all_ok)
         err = e
     if not shard.all_ok(err is None, device):
         raise err if err is not None else RuntimeError("vmap_sharded: another rank failed in its matcher passes")

@@ -205,3 +205,56 @@ def test_whole_program_live_10k_points(tmp_path, bits):
     assert ma == mb
     vx = fileio.read_gma(f"{runs['hip'][3]}/vmap_{t0}_{t1}_vx.GMA", np.float32)
     assert np.isfinite(vx).mean() > 0.9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5: match -> cluster -> dpf0 / dpf1 -> QM capped at 10 sweeps, on the 500x400 grid
+# ---------------------------------------------------------------------------------------------------------------------
+def test_c5_qm_after_a_real_200k_point_match(api, checker, c2):
+    """BASELINE configs[4]: the C2 pair, 200,000 grid points -> the CLI's eight raw-image passes (ocw 7/15/30/40, forward
+    and swapped, MIMC_main.c:261-298) on the GPU -> mimc3_postprocess (clustering, dpf0, dpf1, QM with the sweep cap at 10,
+    MIMC_module.c:893-991 / :1986-2312) on the device, against the same chain of the CPU checker fed the same candidates.
+    The matcher half is checked on a sample of every pass (all 200,000 points of the ocw-16 pass are checked above); the
+    post-processing half runs on the compiled reference where it travelled here, the QM with the cap on the pinned
+    restatement (the reference has no cap parameter; when the capped run converges early both must agree)."""
+    from oracle import oracle as orcmod
+    c, _, _, _ = c2
+    H, W = c.i0.shape
+    n = c.n
+    port = orcmod.Oracle("port") if orcmod.available("port") else checker
+    dp = np.empty((8, n, 3), np.float32)
+    zero = np.zeros(2, np.int32)
+    rng = np.random.default_rng(5)
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        for k, ocw in enumerate((7, 15, 30, 40)):
+            off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
+            dp[2 * k] = ctx.matching_ncc_dlc_2(c.xyuvav, zero, off, uv, ocw)
+            sw = ctx.matching_ncc_dlc_2(c.xyuvav, zero, off, -uv, ocw, swap=True)
+            idx = np.sort(rng.choice(n, 1500, replace=False))
+            soff, suv = subset(off, uv, idx)
+            xs = np.ascontiguousarray(c.xyuvav[idx])
+            assert_bits_equal(dp[2 * k][idx], checker.match(c.i0, c.i1, xs, zero, soff, suv, ocw), f"C5 pass ocw {ocw}")
+            assert_bits_equal(sw[idx], checker.match(c.i1, c.i0, xs, zero, soff, -suv, ocw), f"C5 swapped pass ocw {ocw}")
+            sw[:, :2] = -sw[:, :2]                                        # :288-293
+            dp[2 * k + 1] = sw
+        mps = float(np.float32(c.xyuvav[1, 0] - c.xyuvav[0, 0]))
+        got = ctx.mimc2_postprocess(dp, c.xyuvav, c.dimx, c.dimy, c.dt, c.mpp, mps, qm_max_sweeps=10)
+    # ---- the same chain on the CPU
+    mvn, nclus = checker.cluster_candidates(dp, kmax=32)
+    d0 = checker.get_dpf0(mvn, nclus, c.dimx, c.dimy, 0.6)
+    d1, x1, y1 = checker.get_dpf1(d0, checker.get_ruv_neighbor(c.xyuvav, c.dimx, c.dimy, mps, 3.0), mvn, nclus, c.xyuvav, c.dt, c.mpp)
+    ruv2 = checker.get_ruv_neighbor(c.xyuvav, c.dimx, c.dimy, mps, 5.0)
+    d2, _, _, st = port.qm(d1, x1, y1, ruv2, mvn, nclus, c.xyuvav, max_sweeps=10)
+    assert st is not None and 1 <= int(st[0]) <= 10 and int(st[2]) == 0          # sweeps run; no point hit the T7 definition
+    initial = (mvn[np.arange(n), np.maximum(d1.reshape(-1), 0), 4] < 0.6) & (d1.reshape(-1) >= 0)
+    assert initial.sum() > 1000, "the QM pass has points to investigate"
+    if checker.kind == "reference" and int(st[0]) < 10:                              # converged under the cap: the uncapped reference agrees
+        dr = checker.qm(d1, x1, y1, ruv2, mvn, nclus, c.xyuvav)[0]
+        assert np.array_equal(dr, d2)
+    d2 = d2.reshape(-1)
+    want = np.full((5, n), np.nan, np.float32)
+    ok = d2 >= 0
+    want[:, ok] = mvn[np.arange(n)[ok], d2[ok], :].T
+    assert_bits_equal(got.reshape(5, n), want, "C5 planes (du, dv, var_u, var_v, quality)")
+    assert ok.mean() > 0.9 and (d2 != d1.reshape(-1)).sum() > 0, "the QM pass changed some picks"
