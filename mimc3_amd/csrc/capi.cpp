@@ -12,6 +12,7 @@
 #include "../../include/mimc3_hip.h"
 #include "host_util.h"
 #include "match_kernel.h"
+#include "sat_kernel.h"
 #include "qm_kernel.h"
 #include "n1_kernel.h"
 #include "conv2_kernel.h"
@@ -59,6 +60,7 @@ struct mimc3_ctx {
     DevBuf own_i0, own_i1;              // used when images were uploaded from the host
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
+    DevBuf sat0, sat1, sat_tmp;         // packed summed-area tables of pl0 / pl1 (sum b | sum b^2 | nulls; sat_kernel.hip), built with the planes
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
     DevBuf fail;                        // [0] count, [1..] points the offset-u8 kernel handed to the u16 kernel
     bool u8o_ok = false;                // integer (shift 0) u16 planes whose local range mostly fits 8 bits: try PxU8o first
@@ -260,6 +262,19 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
 
 // Build the zero-bordered u8 planes and prove (on the device) that both images are 8-bit integral.
 // Runs once per image pair; the CLI then reuses the pair for 8 matcher passes (MIMC_main.c:261-300).
+// The summed-area tables of the u8 planes: built once per image pair, right behind the planes (enqueued on the context's stream).
+static int build_u8_tables(mimc3_ctx *c)
+{
+    const int Hp = c->H + 2 * mimc3::kU8Pad;
+    HIP_TRY(c->sat0.reserve(mimc3::sat_bytes(Hp, c->Wp)));
+    HIP_TRY(c->sat1.reserve(mimc3::sat_bytes(Hp, c->Wp)));
+    HIP_TRY(c->sat_tmp.reserve(mimc3::sat_scratch_bytes(Hp, c->Wp)));
+    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl0.p), Hp, c->Wp, static_cast<unsigned long long *>(c->sat0.p), c->sat_tmp.p, c->stream));
+    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl1.p), Hp, c->Wp, static_cast<unsigned long long *>(c->sat1.p), c->sat_tmp.p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // matcher calls may come in on any stream
+    return 0;
+}
+
 static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
 {
     c->u8_ok = false;
@@ -269,7 +284,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
     const size_t bytes = (size_t)(c->H + 2 * pad) * c->Wp;
     if (planes_built) {                 // raw 8-bit DN was widened straight into the planes (mimc3_ctx_set_images_u8)
         c->u8_ok = true; c->u16_ok = false; c->hpl_valid = false; c->u8o_ok = false;
-        return 0;
+        return build_u8_tables(c);
     }
     HIP_TRY(c->pl0.reserve(bytes));
     HIP_TRY(c->pl1.reserve(bytes));
@@ -288,6 +303,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
     c->u16_ok = false;
     c->hpl_valid = false;
     c->u8o_ok = false;
+    if (c->u8_ok) RC_TRY(build_u8_tables(c));
     if (!c->u8_ok) {
         // not 8-bit: is the pair "scaled integer" (12-bit DN, or what GMA_float_conv2 makes of 8-bit images:
         // integers / multiples of 1/8)?  Then the exact u16 kernel applies.
@@ -530,6 +546,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         u.ovf_list = u.ovf_count + 1;
         if (want_u8) {
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
+            u.sat0 = c->sat0.p; u.sat1 = c->sat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
             e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 1;
         } else if (want_u16) {

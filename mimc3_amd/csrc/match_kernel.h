@@ -60,6 +60,9 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     // PxU8o: min | max << 16 of the non-null pixels of every 16x16-pixel tile of the two u16 planes (plane coordinates), or null
     const uint32_t *rt0, *rt1;
     int32_t rt_tw;                                  // tiles per plane row
+    // packed summed-area tables of the two planes (sat_kernel.hip; policies with P::SAT), (Hp + 1) rows of sat_ws entries
+    const void *sat0, *sat1;
+    int32_t sat_ws;
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums
     int32_t debug_stop;             // diagnostics only (env MIMC3_U8_DEBUG_STOP): leave the kernel after phase k; 0 = off

@@ -23,10 +23,12 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 #include <stdio.h>
 #include "match_kernel.h"
+#include "sat_kernel.h"
 
 namespace mimc3 {
 
@@ -76,7 +78,9 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 //   FAST     chip has no null and the cell's box of the window has no null : n, sx, sxx constant
 //   CHIPNULL chip has nulls, box has none                                    : n, sx, sxx constant
 //   GENERAL  the box contains null window pixels                             : all six sums
-enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2 };
+//   XY       like FAST, for planes that come with a summed-area table (sat_kernel.hip): the window-side sums sy, syy of a
+//            null-free box are box sums of the IMAGE and are read from the table; only sxy is accumulated here
+enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2, M_XY = 3 };
 
 template <class S> struct AccT { uint32_t n; S sx, sy, sxx, syy, sxy; };
 
@@ -99,6 +103,11 @@ struct PxU8 {
     static constexpr int BPP = 1, G = 4, LOG2G = 2;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = true;                     // exact integer sums: null corrections may be applied in any order
+    static constexpr bool SAT = true;                         // the planes come with a packed summed-area table (sum b | sum b^2 | nulls)
+    typedef unsigned long long SatT;
+    __device__ static __forceinline__ uint32_t sat_s(SatT q) { return (uint32_t)q & ((1u << kSatSqShift8) - 1u); }
+    __device__ static __forceinline__ uint32_t sat_ss(SatT q) { return (uint32_t)(q >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u); }
+    __device__ static __forceinline__ int sat_nulls(SatT q) { return (int)(q >> kSatNullShift8); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *p; }
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -120,6 +129,7 @@ struct PxU8 {
         // The chip is loop-invariant, so the compiler WOULD hoist every mask out of the evaluation loops (80+
         // VGPRs for the big chips, i.e. spills): the empty asm makes `a` opaque per task (OPQ, big chips only --
         // the small chips have the registers and are faster with the hoisted masks).
+        if (MODE == M_XY) { acc.sxy = dot4(a, bw, acc.sxy); return; }     // pad bytes and nulls are 0 in `a`: no mask at all
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a));
         const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
         if (MODE == M_FAST) {
@@ -185,6 +195,11 @@ struct PxU16 {
     static constexpr int BPP = 2, G = 2, LOG2G = 1;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = true;
+    static constexpr bool SAT = false;
+    typedef unsigned long long SatT;
+    __device__ static __forceinline__ uint32_t sat_s(SatT) { return 0u; }
+    __device__ static __forceinline__ uint32_t sat_ss(SatT) { return 0u; }
+    __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const unsigned short *>(p); }
     typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
@@ -248,6 +263,7 @@ struct PxU16 {
 //      bit-identical to the u16 path's.  Points that do not fit are handed to the u16 kernel through fail_list. -------
 struct PxU8o : PxU8 {
     static constexpr bool SRC16 = true;
+    static constexpr bool SAT = false;
     __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb, int ka, int kb)
     {
         const long long n = sp[0], sx_ = sp[1], sy_ = sp[2], sxx_ = sp[3], syy_ = sp[4], sxy_ = sp[5];
@@ -299,6 +315,11 @@ struct PxF32 {
     static constexpr int BPP = 4, G = 1, LOG2G = 0;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = false;
+    static constexpr bool SAT = false;
+    typedef unsigned long long SatT;
+    __device__ static __forceinline__ uint32_t sat_s(SatT) { return 0u; }
+    __device__ static __forceinline__ uint32_t sat_ss(SatT) { return 0u; }
+    __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const uint32_t *>(p); }
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -494,7 +515,11 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
             const int tt = l + C::LPC * k;
             av = tt < C::REM * C::GPR ? *reinterpret_cast<const volatile uint32_t *>(CH + (C::RF * C::LPC + tt / C::GPR) * C::CPITCH + 4 * (tt % C::GPR)) : 0u;
         }
-        if constexpr (FULLTAIL && MODE == M_FAST) {
+        if constexpr (MODE == M_XY) {
+            // only sxy: the chip dword is 0 in its pad bytes, at its nulls and in the lanes past the last task -- no mask matters
+            P::template task<M_XY, C::OPQ>(acc, av, 0, 0, true, bw, pt.thr);
+        }
+        else if constexpr (FULLTAIL && MODE == M_FAST) {
             // full mask: the caller corrects for pad pixels and lists the tail rows' nulls.  Only the last task has lanes
             // without a dword (they hold a zero chip dword but would still read a window dword): their window is zeroed.
             uint32_t bwt = bw;
@@ -504,7 +529,8 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
         else P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
     }
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
-    acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); acc.sxy = P::template gsum<C::LPC>(acc.sxy);
+    acc.sxy = P::template gsum<C::LPC>(acc.sxy);
+    if (MODE != M_XY) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
     if (MODE == M_GENERAL) {
         acc.n = group_sum<C::LPC>(acc.n); acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx);
     }
@@ -573,6 +599,18 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     pt.thr = p.thr;
     // scaled-integer planes store q = value * 2^s: the sums are rescaled exactly (powers of two) in the finish
     const double sc_chip = p.swap ? p.scale1 : p.scale0, sc_win = p.swap ? p.scale0 : p.scale1;
+    // Summed-area tables of the planes (sat_kernel.hip): the chip's sum a, sum a^2 and null count, the null count of the
+    // window's written area -- two box queries, issued here so that they are in flight while LDS is cleared
+    typedef typename P::SatT SatT;
+    const SatT *sat_chip = nullptr, *sat_win = nullptr;
+    SatT chipQ = 0, winQ = 0;
+    if constexpr (P::SAT) {
+        sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
+        sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
+        chipQ = sat_box(sat_chip, p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
+        winQ = sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * pt.dx2 + (full_win ? 1 : 0), 2 * pt.dy2 + (full_win ? 1 : 0));   // the written area (:869-886)
+    }
+    (void)sat_chip; (void)sat_win; (void)chipQ; (void)winQ;
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
@@ -752,8 +790,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const int x0 = P::G * c - pt.sh;                              // window column of the dword's first pixel
             bool hit = false;                                             // this column holds excluded pixels (x range of the null box)
             constexpr int KB = 8;
-            auto batch = [&](auto tail_c, int rb) __attribute__((always_inline)) {
+            auto batch = [&](auto tail_c, auto nonull_c, int rb) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail_c)::value;
+                constexpr bool NONULL = decltype(nonull_c)::value;       // the table says the written area holds no null: plain copy
                 uint32_t v[KB];
                 [[maybe_unused]] uint2 v16[KB];
                 const uint32_t g0 = (uint32_t)rb * (uint32_t)(P::SRC16 ? gpitch16 : gpitch) + (uint32_t)c;
@@ -771,10 +810,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     v[k] &= keep;                                         // pixels outside the written columns -> 0 (covers T4 column)
                     if (!TAIL || rb + k * rstep < wrows) {
                         *reinterpret_cast<uint32_t *>(wp + k * wstep) = v[k];
-                        susp = susp || P::maybe_excl(v[k], keep, pt.thr);
+                        if constexpr (!NONULL) susp = susp || P::maybe_excl(v[k], keep, pt.thr);
                     }
                 }
-                if (susp) {                                               // rare: count exactly, bound, list
+                if (!NONULL && susp) {                                    // rare: count exactly, bound, list
 #pragma unroll
                     for (int k = 0; k < KB; k++) {
                         const int r = rb + k * rstep;
@@ -800,8 +839,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             };
             int rb = r0;
-            for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, rb);
-            if (rb < wrows) batch(std::true_type{}, rb);
+            if (P::SAT && P::sat_nulls(winQ) == 0) {
+                for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, std::true_type{}, rb);
+                if (rb < wrows) batch(std::true_type{}, std::true_type{}, rb);
+            } else {
+                for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, std::false_type{}, rb);
+                if (rb < wrows) batch(std::true_type{}, std::false_type{}, rb);
+            }
             if (hit) { nbx0 = min(nbx0, x0); nbx1 = max(nbx1, x0 + P::G - 1); }
         }
         // T4: the last window row is never written by the reference -> zeros; also clear the dwords
@@ -864,10 +908,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
                 const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
                 a &= pff;
-                if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);    // the exact counts are taken afterwards, and only then
+                if constexpr (P::SAT) { }                                                            // counts and sums come from the table
+                else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);    // the exact counts are taken afterwards, and only then
                 else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
                 A[i][j] = a;
-                P::chip_acc(SX, SXX, a);
+                if constexpr (!P::SAT) P::chip_acc(SX, SXX, a);
                 if constexpr (C::SPARSE) {
                     if ((j % NW) == wave && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;   // every wave holds the whole chip: each writes a share of the copy
                 }
@@ -882,16 +927,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             uint32_t a = (P::G > 1) ? alignb(chip_dword(rr, j + (P::G > 1 ? 1 : 0)), g0, sa) : g0;
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
-            if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);
+            if constexpr (P::SAT) { }
+            else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);
             else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
             if (C::FULLTAIL && on && j == GPR - 1) padoff = toff[k];
-            P::chip_acc(SX, SXX, a);
+            if constexpr (!P::SAT) P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
                 if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
             }
         }
+        // (with a table the chip's null count is known: only the sparse-correction configs look at the pixels again, to LIST them)
+        if constexpr (P::SAT) chip_susp = C::SPARSE && P::sat_nulls(chipQ) != 0;
         if (P::INTEGER && chip_susp) {                        // rare: the lane's chip dwords again, counted exactly (and listed)
 #pragma unroll
             for (int i = 0; i < C::RF; i++) {
@@ -929,7 +977,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     bad_chip += P::nbad(AT[k], pff, pt.thr);
                     const int nzc = P::nexcl(AT[k], pff, pt.thr);
                     exc_chip += nzc;
-                    if constexpr (C::FULLTAIL) {             // maskless tail tasks: the tail rows' nulls are corrected from the list too
+                    if constexpr (C::FULLTAIL || (P::SAT && C::SPARSE)) {   // maskless tail tasks (and every XY body): the tail rows' nulls are corrected from the list too
                         if (wave == 0 && on && nzc) {
                             int at = atomicAdd(&qcnt[17], nzc);
                             if (at + nzc > kLcCap) qcnt[18] = 1;
@@ -945,8 +993,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             }
         }
-        bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
-        SX = P::template gsum<C::LPC>(SX); SXX = P::template gsum<C::LPC>(SXX);
+        if constexpr (P::SAT) {
+            bad_chip = exc_chip = P::sat_nulls(chipQ);       // null <=> DN == 0 for integral DN: both counts (:622, :723)
+            SX = (Sum)P::sat_s(chipQ); SXX = (Sum)P::sat_ss(chipQ);
+        } else {
+            bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
+            SX = P::template gsum<C::LPC>(SX); SXX = P::template gsum<C::LPC>(SXX);
+        }
     }
     const uint32_t NV = (uint32_t)(C::NPX - exc_chip);       // chip pixels that take part: n, sx, sxx are constants when the box is clean
     const int clean_mode = (exc_chip == 0) ? M_FAST : M_CHIPNULL;
@@ -1101,6 +1154,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         }
         for (int b0 = 0; b0 < cnt; b0 += kSumBatch) {
             const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
+            // thread t finishes cell b0 + t of this batch: its window-side box sums (sum b, sum b^2) come from the table -- four
+            // loads issued now, consumed after the evaluation rounds below
+            [[maybe_unused]] SatT cellQ = 0;
+            if constexpr (P::SAT) {
+                if (tid < nb) {
+                    const uint32_t pk = ids[dir * (b0 + tid)];
+                    cellQ = sat_box(sat_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
+                }
+            }
             for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
                 const int slot = r0 + wave * C::CPR + grp;
                 const bool on = slot < nb;
@@ -1163,7 +1225,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                         // lane-local, modulo 2^32 / 2^64: the reduced totals are exact.  (The u16 policy's lanes accumulate
                         // 32 bits inside a 64-bit sum, so there the correction is subtracted after the body.)
-                        if constexpr (C::FULLTAIL) {         // (before the body: its LDS round trip overlaps the row loads)
+                        if constexpr (C::FULLTAIL && !P::SAT) {         // (before the body: its LDS round trip overlaps the row loads)
                             // the window pixels under the pad bytes of this lane's row-end tail dword leave sy, syy again
                             const int X = pt.sh + cx;
                             const uint32_t sft = (uint32_t)((X & (P::G - 1)) * P::BPP);
@@ -1173,7 +1235,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                         constexpr bool kFold = sizeof(Sum) == 4;
                         if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
-                        acc = eval_round<C, M_FAST, false, C::FULLTAIL>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
+                        // (with a table the body adds nothing to sy, syy: they leave as the corrections alone, the table's box sums
+                        //  -- nulls are zeros in them -- are added in the finish)
+                        acc = eval_round<C, P::SAT ? M_XY : M_FAST, false, C::FULLTAIL>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
                         if (!kFold) { acc.sy -= csy; acc.syy -= csyy; }
                         acc.n = 0u - cn; acc.sx = (Sum)0 - csx; acc.sxx = (Sum)0 - csxx;      // + the point's constants, in the finish
                         done = true;
@@ -1182,25 +1246,34 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                 }
                 if (!done) {
-                    if (mode == M_FAST) acc = eval_round<C, M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    if (mode == M_FAST) acc = eval_round<C, P::SAT ? M_XY : M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                 }
                 Store *sp = sums + 6 * slot;
                 if constexpr (kAPark) {
                     // 16-lane row sums (DPP), then the row leaders add into the slot
-                    const Sum rsy = P::template gsum<16>(acc.sy), rsyy = P::template gsum<16>(acc.syy), rsxy = P::template gsum<16>(acc.sxy);
                     const bool lead = on && (l & 15) == 0;
-                    if (lead) { atomicAdd(&sp[2], P::bits(rsy)); atomicAdd(&sp[4], P::bits(rsyy)); atomicAdd(&sp[5], P::bits(rsxy)); }
+                    const Sum rsxy = P::template gsum<16>(acc.sxy);
+                    if (lead) atomicAdd(&sp[5], P::bits(rsxy));
+                    // sy, syy: the body's sums; with a table only the chip-null corrections of a sparse cell (else the table has it all)
+                    if (!P::SAT || (done ? nLc > 0 : mode != M_FAST)) {
+                        const Sum rsy = P::template gsum<16>(acc.sy), rsyy = P::template gsum<16>(acc.syy);
+                        if (lead) { atomicAdd(&sp[2], P::bits(rsy)); atomicAdd(&sp[4], P::bits(rsyy)); }
+                    }
                     if (six) {
                         const uint32_t rn = group_sum<16>(acc.n);
                         const Sum rsx = P::template gsum<16>(acc.sx), rsxx = P::template gsum<16>(acc.sxx);
                         if (lead) { atomicAdd(&sp[0], (Store)rn); atomicAdd(&sp[1], P::bits(rsx)); atomicAdd(&sp[3], P::bits(rsxx)); }
                     }
                 } else {
-                    if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
-                    if (on && l == 0) {
-                        sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
+                    if (P::SAT && mode == M_FAST) {
+                        if (on && l == 0) sp[5] = P::bits(acc.sxy);     // the other five sums are the point's constants and the table's
+                    } else {
+                        if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
+                        if (on && l == 0) {
+                            sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
+                        }
                     }
                 }
             }
@@ -1214,9 +1287,18 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     // cells whose n, sx, sxx are the point's constants (minus the corrections that were added above)
                     const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)));
                     if (!dense) { v[0] += (Store)NV; v[1] += P::bits(SX); v[3] += P::bits(SXX); }
+                    if constexpr (P::SAT) {
+                        // window-side sums from the table: every cell but the dense ones and the masked CHIPNULL bodies of the
+                        // configs without null lists (those accumulated sy, syy themselves)
+                        const bool sparse_cell = C::SPARSE && sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2));
+                        if (sparse_cell || mode == M_FAST) { v[2] += (Store)P::sat_s(cellQ); v[4] += (Store)P::sat_ss(cellQ); }
+                    }
                     if (C::SPARSE) v[0] = (Store)(uint32_t)v[0];          // n travels as a 32-bit count (corrections wrap modulo 2^32)
 #pragma unroll
                     for (int k = 0; k < 6; k++) sp[k] = 0;                 // the slot is empty for the next batch
+                }
+                if constexpr (P::SAT && !kAPark) {
+                    if (mode == M_FAST) { v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = (Store)P::sat_s(cellQ); v[3] = P::bits(SXX); v[4] = (Store)P::sat_ss(cellQ); }
                 }
                 *vslot(cx, cy) = P::ncc(v, sc_chip, sc_win, ka, kb);
             }
@@ -1729,6 +1811,9 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     static unsigned long long *d_stats = nullptr;
     static const bool want_stats = getenv("MIMC3_U8_STATS") != nullptr;
     static size_t stats_n = 0;
+    static std::mutex stats_mu;                      // diagnostics only: the buffer is shared by every launch of this instantiation
+    std::unique_lock<std::mutex> stats_lock(stats_mu, std::defer_lock);
+    if (want_stats) stats_lock.lock();
     if (want_stats && stats_n < (size_t)nb) {
         if (d_stats) (void)hipFree(d_stats);
         (void)hipMalloc(&d_stats, kStatW * sizeof(unsigned long long) * (size_t)nb);

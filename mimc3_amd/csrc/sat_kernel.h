@@ -1,0 +1,30 @@
+// sat_kernel.h -- packed summed-area tables of the zero-bordered integer planes (internal; see sat_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mimc3 {
+
+// u8 planes: f(b) = b | b^2 << 21 | [b == 0] << 50   (a box of <= 81^2 pixels: sum b < 2^21, sum b^2 < 2^29, nulls < 2^13)
+constexpr int kSatSqShift8 = 21, kSatNullShift8 = 50;
+// u16 planes (q < 4096): f(q) = q | q^2 << 25        (sum q < 2^25, sum q^2 < 2^37); nulls in a second u32 table
+constexpr int kSatSqShift16 = 25;
+
+// entries per table row: the plane's pitch + the zero column
+static inline int sat_pitch(int Wp) { return Wp + 1; }
+size_t sat_bytes(int Hp, int Wp);          // (Hp + 1) x sat_pitch(Wp) x 8
+size_t sat_null_bytes(int Hp, int Wp);     // u16 planes only: (Hp + 1) x sat_pitch(Wp) x 4
+size_t sat_scratch_bytes(int Hp, int Wp);  // column-pass partial sums
+// Enqueue the table build for a plane of Hp rows x Wp pixels (the whole zero-bordered plane) on `s`.
+hipError_t launch_sat_u8(const unsigned char *plane, int Hp, int Wp, unsigned long long *S, void *scratch, hipStream_t s);
+hipError_t launch_sat_u16(const unsigned short *plane, int Hp, int Wp, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s);
+
+// box sum of the w x h pixels whose top-left plane pixel is (x, y): four loads, modular inclusion-exclusion
+template <class T>
+__device__ __forceinline__ T sat_box(const T *__restrict__ S, int Ws, int x, int y, int w, int h)
+{
+    const T *r0 = S + (size_t)y * Ws + x, *r1 = r0 + (size_t)h * Ws;
+    return r1[w] - r0[w] - r1[0] + r0[0];
+}
+
+}  // namespace mimc3

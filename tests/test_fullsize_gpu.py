@@ -221,12 +221,18 @@ def test_c5_qm_after_a_real_200k_point_match(api, checker, c2):
     c, _, _, _ = c2
     H, W = c.i0.shape
     n = c.n
+    # ~30 % of the second image carries a decoy texture (independent of the first image), in 48-px blocks: the
+    # eight candidates of the points there disagree, no cluster reaches the 0.6 quality of get_dpf0, and the QM pass has work
+    rng = np.random.default_rng(5)
+    decoy = synth.texture(H, W, 424242)
+    i1 = c.i1.copy()
+    for by, bx in zip(rng.integers(0, H - 48, 2200), rng.integers(0, W - 48, 2200)):
+        i1[by:by + 48, bx:bx + 48] = decoy[by:by + 48, bx:bx + 48]
     port = orcmod.Oracle("port") if orcmod.available("port") else checker
     dp = np.empty((8, n, 3), np.float32)
     zero = np.zeros(2, np.int32)
-    rng = np.random.default_rng(5)
     with api.Context(0) as ctx:
-        ctx.set_images(c.i0, c.i1)
+        ctx.set_images(c.i0, i1)
         for k, ocw in enumerate((7, 15, 30, 40)):
             off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
             dp[2 * k] = ctx.matching_ncc_dlc_2(c.xyuvav, zero, off, uv, ocw)
@@ -234,8 +240,8 @@ def test_c5_qm_after_a_real_200k_point_match(api, checker, c2):
             idx = np.sort(rng.choice(n, 1500, replace=False))
             soff, suv = subset(off, uv, idx)
             xs = np.ascontiguousarray(c.xyuvav[idx])
-            assert_bits_equal(dp[2 * k][idx], checker.match(c.i0, c.i1, xs, zero, soff, suv, ocw), f"C5 pass ocw {ocw}")
-            assert_bits_equal(sw[idx], checker.match(c.i1, c.i0, xs, zero, soff, -suv, ocw), f"C5 swapped pass ocw {ocw}")
+            assert_bits_equal(dp[2 * k][idx], checker.match(c.i0, i1, xs, zero, soff, suv, ocw), f"C5 pass ocw {ocw}")
+            assert_bits_equal(sw[idx], checker.match(i1, c.i0, xs, zero, soff, -suv, ocw), f"C5 swapped pass ocw {ocw}")
             sw[:, :2] = -sw[:, :2]                                        # :288-293
             dp[2 * k + 1] = sw
         mps = float(np.float32(c.xyuvav[1, 0] - c.xyuvav[0, 0]))
