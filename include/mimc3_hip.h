@@ -106,6 +106,27 @@ int mimc3_match_ncc_dlc_dev(mimc3_ctx *ctx, const double *d_xyuvav, int32_t N, i
 int mimc3_pivot_extent(const int32_t *piv_uv, const int64_t *piv_off, int32_t N,
                        int32_t *max_npiv, int32_t *max_abs_u, int32_t *max_abs_v);
 
+/* ---- a2 on the device.  get_uv_pivot has two halves: the CORRIDOR of a point (theta = atan2(vy, vx), the normalised step,
+ *      the corridor length, MIMC_module.c:559-573) needs libm and is computed on the host, bit-equal to the reference's;
+ *      the pivot LIST (:576-598) is plain IEEE arithmetic on those numbers and is expanded by a kernel.  24 bytes per grid
+ *      point cross PCIe instead of 8 bytes per pivot, and the lists never exist on the host.
+ *      mimc3_pivot_corridors: cor = [N] records of MIMC3_CORRIDOR_BYTES bytes (host; opaque to the caller).
+ *      mimc3_get_uv_pivot_dev: all pointers are device pointers; the context's image size bounds the pivots (as `i1` does in
+ *      the reference).  Same two-call protocol as mimc3_get_uv_pivot (both list pointers NULL = offsets, total and extents
+ *      only); d_piv_uv_neg (optional) receives the negated list main() makes in place for its swapped pass
+ *      (MIMC_main.c:272-279).  extent[3] = what mimc3_pivot_extent returns.  Synchronises `stream` once (a 24-byte read-back).
+ *      Results are bit-equal to mimc3_get_uv_pivot's. ----------------------------------------------------------------- */
+#define MIMC3_CORRIDOR_BYTES 24
+int mimc3_pivot_corridors(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre, void *cor /*[N][24 B]*/);
+int mimc3_get_uv_pivot_dev(mimc3_ctx *ctx, const double *d_xyuvav, const void *d_cor, int32_t N, int32_t ocw,
+                           int64_t *d_piv_off /*[N+1]*/, int32_t *d_piv_uv /*[cap][2] or NULL*/, int32_t *d_piv_uv_neg /*[cap][2] or NULL*/,
+                           int64_t cap, int64_t *total, int32_t extent[3], void *stream);
+/* get_uv_pivot + matching_ncc_dlc_2 in one call, as main() pairs them (MIMC_main.c:264-267, :281-284): host buffers in and
+ * out like mimc3_match_ncc_dlc, but the pivots are made on the device from the uploaded corridors.  `swap` != 0 is the
+ * swapped pass: images exchanged AND the pivots negated (the caller still negates `offset` and the resulting (du, dv)). */
+int mimc3_match_ncc_dlc_geo(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const int32_t offset[2], float dt, float mpp,
+                            float aw_sf, float aw_cre, int32_t ocw, int32_t swap, float *out /*[N][3] host*/);
+
 /* ---- a8: neighbour offsets.  Replaces get_ruv_neighbor (MIMC_module.h:56, :1266-1327).
  *      Host code.  Returns the count in *nn; MIMC3_ECAP if it exceeds cap (pairs). ------------- */
 int mimc3_get_ruv_neighbor(const double *xyuvav, int32_t N, int32_t dimx, int32_t dimy,
@@ -124,6 +145,7 @@ int mimc3_qm_pseudosmooth(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *d
 /* Device-resident variant: d_work must hold mimc3_qm_workspace_bytes(dimy*dimx, max_sweeps) bytes.
  * Runs up to max_sweeps sweeps back-to-back with device-side early-out (no host sync). */
 int64_t mimc3_qm_workspace_bytes(int32_t ngrid, int32_t max_sweeps);
+int32_t mimc3_qm_launches_per_sweep(void);   /* kernel launches enqueued per sweep (2: fit + commit/compare/decide) */
 int mimc3_qm_pseudosmooth_dev(mimc3_ctx *ctx, int32_t dimy, int32_t dimx, int32_t *d_dpf, float *d_dpf_dx,
                               float *d_dpf_dy, const int32_t *d_ruv, int32_t nn, const float *d_mvn, int32_t Kmax,
                               const int32_t *d_nclus, const double *d_xyuvav, int32_t max_sweeps,

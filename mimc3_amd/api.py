@@ -48,6 +48,10 @@ _lib.mimc3_get_uv_pivot.argtypes = [_f64p, C.c_int32, C.c_float, C.c_float, C.c_
 _lib.mimc3_match_ncc_dlc.argtypes = [_vp, _f64p, C.c_int32, _i32p, _i32p, _i64p, C.c_int32, C.c_int32, _f32p]
 _lib.mimc3_match_ncc_dlc_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, _vp, _vp]
+_lib.mimc3_pivot_corridors.argtypes = [_f64p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _vp]
+_lib.mimc3_get_uv_pivot_dev.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64), _i32p, _vp]
+_lib.mimc3_match_ncc_dlc_geo.argtypes = [_vp, _f64p, C.c_int32, _i32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _f32p]
+_lib.mimc3_qm_launches_per_sweep.restype = C.c_int32
 _lib.mimc3_pivot_extent.argtypes = [_i32p, _i64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32)]
 _lib.mimc3_get_ruv_neighbor.argtypes = [_f64p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _i32p, C.c_int32,
@@ -178,6 +182,21 @@ def get_uv_pivot_counts(xyuvav, dt, mpp, ocw, H, W, aw_sf=1.8, aw_cre=10.0):
     tot = C.c_int64(0)
     _check(_lib.mimc3_get_uv_pivot(xy, xy.shape[0], dt, mpp, aw_sf, aw_cre, ocw, H, W, off, None, 0, C.byref(tot)), "get_uv_pivot")
     return off
+
+
+CORRIDOR_BYTES = 24      # MIMC3_CORRIDOR_BYTES
+
+
+def pivot_corridors(xyuvav, dt, mpp, aw_sf=1.8, aw_cre=10.0):
+    """the host half of get_uv_pivot (MIMC_module.c:559-573): [N] opaque 24-byte corridor records (uint8 [N][24])"""
+    xy = np.ascontiguousarray(xyuvav, np.float64)
+    cor = np.zeros((xy.shape[0], CORRIDOR_BYTES), np.uint8)
+    _check(_lib.mimc3_pivot_corridors(xy, xy.shape[0], dt, mpp, aw_sf, aw_cre, cor.ctypes.data), "pivot_corridors")
+    return cor
+
+
+def qm_launches_per_sweep():
+    return int(_lib.mimc3_qm_launches_per_sweep())
 
 
 def pivot_extent(piv_off, piv_uv):
@@ -359,6 +378,23 @@ class Context:
                                         np.ascontiguousarray(piv_uv, np.int32), np.ascontiguousarray(piv_off, np.int64),
                                         ocw, 1 if swap else 0, out), "matching_ncc_dlc_2")
         return out
+
+    def matching_ncc_dlc_geo(self, xyuvav, offset, dt, mpp, ocw, swap=False, aw_sf=1.8, aw_cre=10.0):
+        """get_uv_pivot + matching_ncc_dlc_2 in one call: corridors from the host, pivot lists made on the device.
+        swap=True = the swapped pass (images exchanged, pivots negated; the caller negates offset and (du, dv))."""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        out = np.empty((xy.shape[0], 3), np.float32)
+        _check(_lib.mimc3_match_ncc_dlc_geo(self._h, xy, xy.shape[0], np.ascontiguousarray(offset, np.int32), dt, mpp, aw_sf, aw_cre, ocw,
+                                            1 if swap else 0, out), "matching_ncc_dlc_geo")
+        return out
+
+    def get_uv_pivot_dev(self, d_xyuvav, d_cor, n, ocw, d_piv_off, d_piv_uv=None, d_piv_uv_neg=None, cap=0, stream=0):
+        """device half of get_uv_pivot on device buffers; returns (total, (max_npiv, max_abs_u, max_abs_v))"""
+        total = C.c_int64(0)
+        ext = np.zeros(3, np.int32)
+        _check(_lib.mimc3_get_uv_pivot_dev(self._h, d_xyuvav, d_cor, n, ocw, d_piv_off, d_piv_uv, d_piv_uv_neg, cap, C.byref(total), ext, stream),
+               "get_uv_pivot_dev")
+        return total.value, (int(ext[0]), int(ext[1]), int(ext[2]))
 
     def matching_ncc_dlc_2_dev(self, d_xyuvav, n, offset, d_piv_uv, d_piv_off, extent, ocw, d_out, stream=0, swap=False):
         """Device-pointer variant (enqueue only). extent = pivot_extent(...) = (max_npiv, max|u|, max|v|)."""

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include "host_util.h"
 #include "match_kernel.h"
 #include "sat_kernel.h"
+#include "pivot_kernel.h"
 #include "qm_kernel.h"
 #include "n1_kernel.h"
 #include "conv2_kernel.h"
@@ -76,6 +78,7 @@ struct mimc3_ctx {
     int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
     int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
+    DevBuf pcor, pcnt, pext;            // device pivots: corridors [N] x 24 B, counts [N], extents + total (24 B)
     DevBuf qm_io, qm_work;              // QM staging / workspace
     DevBuf n1_io, n1_work;              // clustering / dpf0 / dpf1 staging and workspace
     const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
@@ -94,7 +97,7 @@ struct mimc3_ctx {
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     void *hslot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mimc3_ctx_host_workspace: pinned host scratch
     size_t hslot_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    DevBuf slot[16];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
+    DevBuf slot[24];                    // mimc3_ctx_workspace: named scratch the drivers built on the ABI keep across calls
     bool no_u8o = false;                // internal (CP stage): never try the per-point-offset u8 form on this context's pairs
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
@@ -624,8 +627,91 @@ extern "C" int mimc3_match_ncc_dlc(mimc3_ctx *c, const double *xyuvav, int32_t N
 }
 
 // ---------------------------------------------------------------------------------------------
+// a2 on the device: pivot lists expanded from per-point corridors (pivot_kernel.hip)
+// ---------------------------------------------------------------------------------------------
+static_assert(sizeof(mimc3::CorridorPOD) == sizeof(mimc3::CorridorDev) && offsetof(mimc3::CorridorPOD, length) == offsetof(mimc3::CorridorDev, length),
+              "host and device corridor records share one layout");
+
+extern "C" int mimc3_pivot_corridors(const double *xyuvav, int32_t N, float dt, float mpp, float aw_sf, float aw_cre, void *cor)
+{
+    if (!xyuvav || !cor || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_pivot_corridors: bad argument");
+    mimc3::pivot_corridors(xyuvav, N, dt, mpp, aw_sf, aw_cre, static_cast<mimc3::CorridorPOD *>(cor));
+    return 0;
+}
+
+// counts + offsets, then ONE 24-byte read-back (synchronises `s`): total pivots and the extents a matcher launch is sized by
+static int pivots_count(mimc3_ctx *c, const double *d_xy, const void *d_cor, int32_t N, int32_t ocw, int64_t *d_off, hipStream_t s, int64_t *total,
+                        int32_t ext[3])
+{
+    HIP_TRY(c->pcnt.reserve(sizeof(int32_t) * (size_t)N));
+    HIP_TRY(c->pext.reserve(64));
+    HIP_TRY(mimc3::launch_pivot_count(d_xy, static_cast<const mimc3::CorridorDev *>(d_cor), N, ocw, c->H, c->W, static_cast<int32_t *>(c->pcnt.p), d_off,
+                                      static_cast<int32_t *>(c->pext.p), s));
+    int32_t h[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->pext.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int64_t tot = 0;
+    std::memcpy(&tot, &h[4], sizeof(tot));
+    *total = tot;
+    ext[0] = h[0]; ext[1] = h[1]; ext[2] = h[2];
+    if (h[3]) return mimc3::fail(MIMC3_EBOUNDS, "mimc3_get_uv_pivot_dev: a grid point has zero pivots (too close to the image edge)");
+    return 0;
+}
+
+extern "C" int mimc3_get_uv_pivot_dev(mimc3_ctx *c, const double *d_xyuvav, const void *d_cor, int32_t N, int32_t ocw, int64_t *d_piv_off,
+                                      int32_t *d_piv_uv, int32_t *d_piv_uv_neg, int64_t cap, int64_t *total, int32_t extent[3], void *stream)
+{
+    if (!c || !d_xyuvav || !d_cor || !d_piv_off || !total || !extent || N <= 0 || ocw < 1)
+        return mimc3::fail(MIMC3_EINVAL, "mimc3_get_uv_pivot_dev: bad argument");
+    if (c->H <= 0 || c->W <= 0) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_uv_pivot_dev: images not set (the image size bounds the pivots)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RC_TRY(pivots_count(c, d_xyuvav, d_cor, N, ocw, d_piv_off, s, total, extent));
+    if (!d_piv_uv && !d_piv_uv_neg) return 0;               // two-call protocol, as mimc3_get_uv_pivot
+    if (cap < *total) return mimc3::fail(MIMC3_ECAP, "mimc3_get_uv_pivot_dev: pivot capacity too small");
+    HIP_TRY(mimc3::launch_pivot_fill(static_cast<const mimc3::CorridorDev *>(d_cor), d_piv_off, N, d_piv_uv, d_piv_uv_neg, s));
+    return 0;
+}
+
+// get_uv_pivot + matching_ncc_dlc_2 (MIMC_main.c:264-267 / :281-284) in one call; only 24 bytes of corridor per point are uploaded
+extern "C" int mimc3_match_ncc_dlc_geo(mimc3_ctx *c, const double *xyuvav, int32_t N, const int32_t offset[2], float dt, float mpp, float aw_sf,
+                                       float aw_cre, int32_t ocw, int32_t swap, float *out)
+{
+    if (!c || !xyuvav || !offset || !out || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_geo: bad argument");
+    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_geo: images not set");
+    for (int32_t g = 0; g < N; ++g) {                       // (see mimc3_match_ncc_dlc: the reference reads out of bounds here)
+        const int32_t u0 = (int32_t)xyuvav[6 * (size_t)g + 2], v0 = (int32_t)xyuvav[6 * (size_t)g + 3];
+        if (u0 - ocw < 0 || u0 + ocw >= c->W || v0 - ocw < 0 || v0 + ocw >= c->H)
+            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc_geo: grid point " + std::to_string(g) + " chip leaves the image");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    void *hcor = nullptr;
+    RC_TRY(mimc3_ctx_host_workspace(c, 7, sizeof(mimc3::CorridorPOD) * (size_t)N, &hcor));      // pinned, kept across calls
+    mimc3::pivot_corridors(xyuvav, N, dt, mpp, aw_sf, aw_cre, static_cast<mimc3::CorridorPOD *>(hcor));
+    HIP_TRY(c->xy.reserve(sizeof(double) * 6 * (size_t)N));
+    HIP_TRY(c->pcor.reserve(sizeof(mimc3::CorridorPOD) * (size_t)N));
+    HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + 1)));
+    HIP_TRY(c->out.reserve(sizeof(float) * 3 * (size_t)N));
+    RC_TRY(h2d_copy(c, c->xy.p, xyuvav, sizeof(double) * 6 * (size_t)N));
+    RC_TRY(h2d_copy(c, c->pcor.p, hcor, sizeof(mimc3::CorridorPOD) * (size_t)N));
+    int64_t total = 0;
+    int32_t ext[3] = {0, 0, 0};
+    RC_TRY(pivots_count(c, static_cast<const double *>(c->xy.p), c->pcor.p, N, ocw, static_cast<int64_t *>(c->poff.p), c->stream, &total, ext));
+    HIP_TRY(c->puv.reserve(sizeof(int32_t) * 2 * (size_t)total));
+    int32_t *uv = static_cast<int32_t *>(c->puv.p);
+    HIP_TRY(mimc3::launch_pivot_fill(static_cast<const mimc3::CorridorDev *>(c->pcor.p), static_cast<const int64_t *>(c->poff.p), N, swap ? nullptr : uv,
+                                     swap ? uv : nullptr, c->stream));
+    int rc = mimc3_match_ncc_dlc_dev(c, static_cast<const double *>(c->xy.p), N, offset[0], offset[1], uv, static_cast<const int64_t *>(c->poff.p), ext[0],
+                                     ext[1], ext[2], ocw, swap, static_cast<float *>(c->out.p), c->stream);
+    if (rc) return rc;
+    return d2h_copy(c, out, c->out.p, sizeof(float) * 3 * (size_t)N);
+}
+
+// ---------------------------------------------------------------------------------------------
 // QM pseudo-smoothing
 // ---------------------------------------------------------------------------------------------
+extern "C" int32_t mimc3_qm_launches_per_sweep(void) { return mimc3::kQmLaunchesPerSweep; }
+
 extern "C" int64_t mimc3_qm_workspace_bytes(int32_t ngrid, int32_t max_sweeps)
 {
     if (ngrid <= 0 || max_sweeps <= 0) return 0;
@@ -1242,7 +1328,7 @@ extern "C" int mimc3_dpf_to_vxyexyqual_dev(mimc3_ctx *c, const int32_t *d_dpf, c
 
 extern "C" int mimc3_ctx_workspace(mimc3_ctx *c, int32_t slot, size_t bytes, void **d_ptr)
 {
-    if (!c || !d_ptr || slot < 0 || slot >= 16) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_workspace: bad argument");
+    if (!c || !d_ptr || slot < 0 || slot >= 24) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_workspace: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->slot[slot].reserve(bytes ? bytes : 1));
     *d_ptr = c->slot[slot].p;

@@ -72,8 +72,11 @@ namespace {
 // points are independent: the passes run on a few host threads
 template <class Body> void run_threads(int32_t N, Body &&body)
 {
+    // (at least ~4,000 points per thread: below that the thread start costs more than the loop)
     unsigned nt = N >= 20000 ? std::thread::hardware_concurrency() : 1;
-    nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+    const unsigned by_work = (unsigned)(N / 4000) + 1;
+    nt = nt > 64 ? 64 : (nt < 1 ? 1 : nt);
+    nt = nt > by_work ? by_work : nt;
     if (nt == 1) { body(0, N); return; }
     std::vector<std::thread> th;
     const int32_t step = (N + (int32_t)nt - 1) / (int32_t)nt;

@@ -30,6 +30,13 @@
 #include "match_kernel.h"
 #include "sat_kernel.h"
 
+#ifndef MIMC3_XY_ACC
+#define MIMC3_XY_ACC 2          // independent dot4 chains of the sxy-only body (tuning switch)
+#endif
+#ifndef MIMC3_SAT_DEFER
+#define MIMC3_SAT_DEFER 1       // table look-ups of a batch: keep the four corners in registers, combine them in the finish
+#endif
+
 namespace mimc3 {
 
 static constexpr float kUnknown = 3.0f;
@@ -129,7 +136,11 @@ struct PxU8 {
         // The chip is loop-invariant, so the compiler WOULD hoist every mask out of the evaluation loops (80+
         // VGPRs for the big chips, i.e. spills): the empty asm makes `a` opaque per task (OPQ, big chips only --
         // the small chips have the registers and are faster with the hoisted masks).
-        if (MODE == M_XY) { acc.sxy = dot4(a, bw, acc.sxy); return; }     // pad bytes and nulls are 0 in `a`: no mask at all
+        if (MODE == M_XY) {     // pad bytes and nulls are 0 in `a`: no mask at all.  (`static_pad` doubles as the accumulator choice:
+            // a single chain of dependent dot4 would stall on its own latency; the caller alternates two and adds them at the end)
+            if (static_pad) acc.sxy = dot4(a, bw, acc.sxy); else acc.sy = dot4(a, bw, acc.sy);
+            return;
+        }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a));
         const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ff_from80(nz80(a));
         if (MODE == M_FAST) {
@@ -454,6 +465,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
                                           const unsigned char *CH = nullptr)
 {
     typedef typename C::P P;
+    [[maybe_unused]] const typename P::Sum sy_in = acc.sy;
     const int X = pt.sh + cx;                                       // pixel offset of the box inside the LDS row
     const uint32_t s = (uint32_t)((X & (P::G - 1)) * P::BPP);       // byte phase inside the first dword
     const unsigned char *base = W + cy * pt.PW + 4 * (X >> P::LOG2G);
@@ -501,7 +513,8 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
             const uint32_t bw = (P::G > 1) ? alignb(w[j + (P::G > 1 ? 1 : 0)], w[j], s) : w[j];
             const uint32_t p01 = (j == C::GPR - 1) ? C::LAST01 : 0x01010101u;
             const uint32_t pff = (j == C::GPR - 1) ? C::LASTFF : 0xffffffffu;
-            P::template task<MODE, C::OPQ>(acc, A[i][j], p01, pff, true, bw, pt.thr);
+            if constexpr (MODE == M_XY) P::template task<M_XY, C::OPQ>(acc, A[i][j], 0, 0, (MIMC3_XY_ACC < 2) || ((i * C::GPR + j) & 1) == 0, bw, pt.thr);
+            else P::template task<MODE, C::OPQ>(acc, A[i][j], p01, pff, true, bw, pt.thr);
         }
     }
     }
@@ -517,7 +530,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
         }
         if constexpr (MODE == M_XY) {
             // only sxy: the chip dword is 0 in its pad bytes, at its nulls and in the lanes past the last task -- no mask matters
-            P::template task<M_XY, C::OPQ>(acc, av, 0, 0, true, bw, pt.thr);
+            P::template task<M_XY, C::OPQ>(acc, av, 0, 0, (MIMC3_XY_ACC < 2) || (k & 1) == 0, bw, pt.thr);
         }
         else if constexpr (FULLTAIL && MODE == M_FAST) {
             // full mask: the caller corrects for pad pixels and lists the tail rows' nulls.  Only the last task has lanes
@@ -528,6 +541,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
         }
         else P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
     }
+    if constexpr (MODE == M_XY && MIMC3_XY_ACC >= 2 && !C::CHIP_LDS) { acc.sxy += acc.sy - sy_in; acc.sy = sy_in; }   // fold the second chain (sy carried the caller's corrections in)
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE != M_XY) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
@@ -1156,11 +1170,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
             // thread t finishes cell b0 + t of this batch: its window-side box sums (sum b, sum b^2) come from the table -- four
             // loads issued now, consumed after the evaluation rounds below
-            [[maybe_unused]] SatT cellQ = 0;
+            // (the four corners stay in registers until the finish: combining them here would wait for the loads right away)
+            [[maybe_unused]] SatT cellQ = 0, q00 = 0, q01 = 0, q10 = 0, q11 = 0;
             if constexpr (P::SAT) {
-                if (tid < nb) {
+                const bool need = mode == M_FAST || (C::SPARSE && sparse_on);
+                if (need && tid < nb) {
                     const uint32_t pk = ids[dir * (b0 + tid)];
-                    cellQ = sat_box(sat_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
+                    const SatT *r0 = sat_win + (size_t)(wv0 + (int)((pk >> 8) & 0xffu)) * p.sat_ws + (wu0 + (int)(pk & 0xffu)), *r1 = r0 + (size_t)CW * p.sat_ws;
+                    q00 = r0[0]; q01 = r0[CW]; q10 = r1[0]; q11 = r1[CW];
+                    if (!MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
                 }
             }
             for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
@@ -1279,6 +1297,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             }
             __syncthreads();
             if (tid < nb) {
+                if (MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
                 const uint32_t pk = ids[dir * (b0 + tid)];
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 Store *sp = sums + 6 * tid;

@@ -25,7 +25,7 @@
 namespace {
 
 // context scratch slots (mimc3_ctx_workspace) used by the drivers in this file and in mgpu.cpp
-enum { kSlotPost = 0, kSlotXy = 1, kSlotOut5 = 3, kSlotDp = 4, kSlotXyFull = 5, kSlotPiv0 = 11 /* ..14: one per chip size */ };
+enum { kSlotPost = 0, kSlotXy = 1, kSlotOut5 = 3, kSlotDp = 4, kSlotXyFull = 5, kSlotPiv0 = 11 /* ..14: one per chip size */, kSlotPivOff0 = 16 /* ..19 */ };
 
 // a typed view of a piece of context scratch
 struct View {
@@ -146,68 +146,57 @@ int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res)
     return 0;
 }
 
-HostPivots::~HostPivots() {}     // the payload lives in the context's pinned host scratch (mimc3_ctx_host_workspace, slot = chip size index)
+HostPivots::~HostPivots() {}     // everything lives in the context's scratch slots
 
-// pivots of the four chip sizes (:264, :316) for the points xs[0..ns): host geometry (libm-exact, threaded) that depends
-// on nothing the CP stage produces; payload in pinned memory.  Safe to call from a worker thread (`device` = the device
-// whose context will upload them); the error text is returned because mimc3_last_error() is thread-local.
+// pivots of the four chip sizes (:264, :316) for the points xs[0..ns).  The corridor of a point (atan2 / cos / sin: libm,
+// host, threaded, once for all four chip sizes) depends on nothing the CP stage produces; 24 bytes per point are uploaded and
+// the lists -- forward and negated (:272-279) -- are expanded on the device (pivot_kernel.hip), on an auxiliary stream, so that
+// all of it overlaps the control-point stage.  Safe to call from a worker thread; the error text is returned because
+// mimc3_last_error() is thread-local.
 int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W,
                      HostPivots hp[4], std::string &err)
 {
+    (void)H; (void)W;                                        // (the context's image size bounds the pivots)
     if (ns <= 0) return 0;
-    // the four chip sizes are independent: one host thread each (every one of them fans out again inside mimc3_get_uv_pivot)
-    int rcs[4] = {0, 0, 0, 0};
-    std::string errs[4];
-    // the corridor of a point (its atan2 / sin / cos) is the same for all four chip sizes: once per point
     static const bool tm = getenv("MIMC3_VMAP_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](int c, const char *w) { if (tm) fprintf(stderr, "[mimc3 piv %d] %-10s at %.2f ms\n", c, w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
-    std::vector<mimc3::CorridorPOD> cor((size_t)ns);
-    mimc3::pivot_corridors(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, cor.data());
-    lap(-1, "corridors");
-    // device copies: forward and negated (:272-279) pivots + offsets, on a stream of this thread's own
-    auto upload = [&](int c) -> int {
+    auto body = [&]() -> int {
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t tb = 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), ob = 8 * ((size_t)ns + 1);
-        void *base = nullptr;
-        RC_TRY(mimc3_ctx_workspace(ctx, kSlotPiv0 + c, 2 * al(tb) + al(ob), &base));      // (also selects the context's device for this thread)
-        char *cur = static_cast<char *>(base);
-        hp[c].d_uv = reinterpret_cast<int32_t *>(cur); cur += al(tb);
-        hp[c].d_uvn = reinterpret_cast<int32_t *>(cur); cur += al(tb);
-        hp[c].d_off = reinterpret_cast<int64_t *>(cur);
-        hipStream_t st = static_cast<hipStream_t>(mimc3_ctx_aux_stream(ctx, c));
+        void *hcor = nullptr, *base = nullptr;
+        RC_TRY(mimc3_ctx_host_workspace(ctx, 0, MIMC3_CORRIDOR_BYTES * (size_t)ns, &hcor));          // pinned, kept across calls
+        RC_TRY(mimc3_pivot_corridors(xs, ns, dt, mpp, p->aw_sf, p->aw_cre, hcor));
+        lap(-1, "corridors");
+        RC_TRY(mimc3_ctx_workspace(ctx, kSlotXy, al(48 * (size_t)ns) + al(MIMC3_CORRIDOR_BYTES * (size_t)ns), &base));   // (also selects the context's device for this thread)
+        double *d_xy = static_cast<double *>(base);
+        void *d_cor = static_cast<char *>(base) + al(48 * (size_t)ns);
+        hipStream_t st = static_cast<hipStream_t>(mimc3_ctx_aux_stream(ctx, 0));
         if (!st) return mimc3::fail(MIMC3_ESTATE, "mimc3_vmap: the context has no auxiliary stream");
-        hipError_t e = hipMemcpyAsync(hp[c].d_uv, hp[c].uv, 8 * (size_t)hp[c].total, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hp[c].d_off, hp[c].off.data(), ob, hipMemcpyHostToDevice, st);
-        int rc = e == hipSuccess ? mimc3_negate_pivots_dev(ctx, hp[c].d_uv, hp[c].d_uvn, hp[c].total, st) : hip_fail(e, "pivot upload");
-        e = hipStreamSynchronize(st);
-        if (!rc && e != hipSuccess) rc = hip_fail(e, "pivot upload");
-        return rc;
+        HIP_TRY(hipMemcpyAsync(d_xy, xs, 48 * (size_t)ns, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_cor, hcor, MIMC3_CORRIDOR_BYTES * (size_t)ns, hipMemcpyHostToDevice, st));
+        for (int c = 0; c < 4; c++) {
+            // offsets first (they size the lists): into a buffer of their own, then lists + negated lists behind them
+            void *ob = nullptr;
+            RC_TRY(mimc3_ctx_workspace(ctx, kSlotPivOff0 + c, 8 * ((size_t)ns + 1), &ob));
+            hp[c].d_off = static_cast<int64_t *>(ob);
+            int32_t ext[3] = {0, 0, 0};
+            RC_TRY(mimc3_get_uv_pivot_dev(ctx, d_xy, d_cor, ns, p->vec_ocw[c], hp[c].d_off, nullptr, nullptr, 0, &hp[c].total, ext, st));
+            const size_t tb = al(8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1));
+            void *ub = nullptr;
+            RC_TRY(mimc3_ctx_workspace(ctx, kSlotPiv0 + c, 2 * tb, &ub));
+            hp[c].d_uv = static_cast<int32_t *>(ub);
+            hp[c].d_uvn = reinterpret_cast<int32_t *>(static_cast<char *>(ub) + tb);
+            RC_TRY(mimc3_get_uv_pivot_dev(ctx, d_xy, d_cor, ns, p->vec_ocw[c], hp[c].d_off, hp[c].d_uv, hp[c].d_uvn, hp[c].total, &hp[c].total, ext, st));
+            hp[c].mn = ext[0]; hp[c].mu = ext[1]; hp[c].mv = ext[2];
+            lap(c, "lists");
+        }
+        hp[0].d_xy = d_xy;
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
     };
-    auto one = [&](int c) {
-        hp[c].off.resize((size_t)ns + 1);
-        int32_t ext[3] = {0, 0, 0};
-        int rc = mimc3::get_uv_pivot_cor(cor.data(), xs, ns, p->vec_ocw[c], H, W, hp[c].off.data(), nullptr, 0, &hp[c].total);
-        lap(c, "count");
-        if (!rc) rc = mimc3_ctx_host_workspace(ctx, c, 8 * (size_t)(hp[c].total > 0 ? hp[c].total : 1), &hp[c].uv);   // pinned, kept across calls
-        if (!rc) rc = mimc3::get_uv_pivot_cor(cor.data(), xs, ns, p->vec_ocw[c], H, W, hp[c].off.data(),
-                                              static_cast<int32_t *>(hp[c].uv), hp[c].total, &hp[c].total, ext);
-        if (!rc) { hp[c].mn = ext[0]; hp[c].mu = ext[1]; hp[c].mv = ext[2]; }
-        lap(c, "fill");
-        if (!rc) rc = upload(c);
-        lap(c, "upload");
-        if (rc) { errs[c] = mimc3_last_error(); rcs[c] = rc; }          // the message is thread-local: carry it over
-    };
-    if (ns >= 20000) {
-        std::thread th[3] = {std::thread(one, 1), std::thread(one, 2), std::thread(one, 3)};
-        one(0);
-        for (auto &t : th) t.join();
-    } else {
-        for (int c = 0; c < 4; c++) one(c);
-    }
-    for (int c = 0; c < 4; c++)
-        if (rcs[c]) { err = errs[c]; return rcs[c]; }
-    return 0;
+    const int rc = body();
+    if (rc) err = mimc3_last_error();                        // the message is thread-local: carry it over
+    return rc;
 }
 
 // CP offset on the whole grid (:240-256): fills res->cp_status / offset_cp and flag_cp
@@ -250,8 +239,8 @@ int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t 
     }
     const size_t n = (size_t)ns;
     void *d_xy = nullptr;
-    RC_TRY(mimc3_ctx_workspace(ctx, kSlotXy, 48 * n, &d_xy));
-    HIP_TRY(hipMemcpyAsync(d_xy, xs, 48 * n, hipMemcpyHostToDevice, s));
+    d_xy = hp[0].d_xy;                                        // uploaded with the corridors (vmap_host_pivots)
+    if (!d_xy) return mimc3::fail(MIMC3_ESTATE, "mimc3_vmap: pivots were not made");
 
     // ---- pivots: forward and negated copies are resident already (uploaded by vmap_host_pivots' threads)
     struct Piv { int32_t *uv, *uvn; int64_t *off; };

@@ -8,15 +8,13 @@
 
 namespace mimc3 {
 
-// CSR pivots of one chip size for a set of points: made on the host (payload in the context's pinned host scratch) and
-// uploaded from the same thread, so that all of it overlaps the control-point stage
+// CSR pivots of one chip size for a set of points, resident on the device (context scratch): made from host corridors by the
+// pivot kernels on an auxiliary stream, so that all of it overlaps the control-point stage
 struct HostPivots {
-    std::vector<int64_t> off;
-    void *uv = nullptr;
     int64_t total = 0;
-    // device copies in the context's scratch (uploaded by the thread that made them): pivots, negated pivots (:272-279), offsets
-    int32_t *d_uv = nullptr, *d_uvn = nullptr;
+    int32_t *d_uv = nullptr, *d_uvn = nullptr;       // pivots, negated pivots (:272-279)
     int64_t *d_off = nullptr;
+    double *d_xy = nullptr;                          // [0] only: the points' xyuvav rows, uploaded with the corridors
     int32_t mn = 0, mu = 0, mv = 0;
     HostPivots() = default;
     HostPivots(const HostPivots &) = delete;
