@@ -36,6 +36,16 @@ KERNEL_NAMES = {"u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dl
 DTYPES = {"u8_exact": "u8", "u16_scaled": "u16", "u8_offset": "u8"}
 
 
+def kernel_source_sha16():
+    """identifies the matcher kernel source the PMC figures in profiles/traffic_latest.json were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("match_px_kernel.hip", "match_kernel.h", "sat_kernel.h"):
+        with open(os.path.join(ROOT, "mimc3_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(piv_off, piv_uv, ocw):
     """B = 4(2ocw+1)^2 + 4*Dy2*Dx2 + 48 + 8*npiv + 12 per grid point, summed."""
     npiv = (piv_off[1:] - piv_off[:-1]).astype(np.int64)
@@ -171,7 +181,7 @@ def main():
         leg = Leg(torch, api, dev, xy_all, piv_off, piv_uv, n_all)
         elapsed, kern_ms = timed(torch, dist, world, dev, make_step(leg), args.steps, args.warmup)
         alg_bytes = algorithmic_bytes(piv_off, piv_uv, case.ocw)
-        n_job, n_rank0, scaling = n_all, n_all, "weak"
+        n_job, n_rank0, scaling = n_all, n_all, "n/a"        # one rank: nothing scales
         got = leg.d_out.cpu().numpy()
         path = ctx.last_path()
     else:
@@ -242,10 +252,22 @@ def main():
                            "note": "pair upload incl. device-side widening + plane build; raw = 1 B/px as the 8-bit TIFF holds it"},
         }
         res.update(result)
-        try:   # HBM bytes per launch measured by rocprofv3 PMC passes of this same command (profiles/)
+        try:   # counters of this kernel from rocprofv3 PMC passes of this same command (tools/profile.sh + tools/pmc_to_json.py)
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[args.config][kname]
-            res["roofline"]["traffic"] = tr["bytes"]
-            res["roofline"]["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; measured in separate --pmc passes, not in this run)"
+            rf = res["roofline"]
+            rf["traffic"] = tr["bytes"]
+            rf["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; measured in separate --pmc passes, not in this run)"
+            # SURVEY 8(d)'s secondary bounds: the kernel is VALU-issue-bound, not HBM-bound (traffic << algorithmic bytes)
+            for k in ("valu_per_point", "salu_per_point", "lds_per_point", "valu_busy", "lds_active_frac"):
+                if k in tr:
+                    rf[k] = tr[k]
+            if "lds_per_point" in tr and kern_ms > 0:
+                # LDS wave-instructions x 64 lanes x 4 B (the kernel's LDS traffic is ds_read_b32 / ds_read2_b32) over the live kernel time;
+                # the ds_read_b32 peak of the chip is ~75 TB/s (MI355X_MICROARCH.md, LDS)
+                rf["lds_bytes_per_s"] = tr["lds_per_point"] * 256.0 * n_rank0 / (kern_ms * 1e-3)
+                rf["lds_peak_bytes_per_s"] = 75e12
+            rf["pmc_kernel_sha16"] = tr.get("kernel_sha16")
+            rf["pmc_stale"] = tr.get("kernel_sha16") != kernel_source_sha16()     # True: the kernel source changed after the PMC passes
         except Exception:
             pass
         valid = got[:, 2] > -2.5
@@ -253,7 +275,7 @@ def main():
                         "median_du_dv": [float(np.nanmedian(got[:, 0])), float(np.nanmedian(got[:, 1]))],
                         "true_shift": list(case.shift)}
         if world == 1:
-            res["incl_io"] = io_leg(api, ctx, case, xy_all, piv_off, piv_uv, min(args.steps, 10))
+            res["incl_io"] = io_leg(api, ctx, case, xy_all, piv_off, piv_uv, min(args.steps, 10), got)
             res["value_incl_io"] = res["incl_io"]["value"]
             cpu = None
             if not args.no_cpu_baseline:
@@ -272,21 +294,34 @@ def main():
         dist.destroy_process_group()
 
 
-def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps):
-    """one pass INCLUDING the xyuvav / pivot upload and the result download (host entry point
-    mimc3_match_ncc_dlc from pinned host arrays; the images stay resident as in the CLI's 32-pass schedule)."""
-    H, W = case.i0.shape
+def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
+    """one pass INCLUDING everything the host hands over and takes back per pass; the images stay resident
+    as in the CLI's 32-pass schedule.  Two forms, both from pinned host arrays:
+      geo  mimc3_match_ncc_dlc_geo: get_uv_pivot + matching_ncc_dlc_2 in one call -- the host computes the corridor of every
+           point (the libm half of get_uv_pivot: INSIDE the timed step), uploads xyuvav + 24 B of corridor per point, the
+           pivot lists are expanded on the device;
+      csr  mimc3_match_ncc_dlc: the pivot CSR made beforehand on the host is uploaded with xyuvav (round 2's form)."""
+    n = xy.shape[0]
     pxy = api.pinned_empty(xy.shape, np.float64); pxy[:] = xy
     puv = api.pinned_empty(piv_uv.shape, np.int32); puv[:] = piv_uv
     poff = api.pinned_empty(piv_off.shape, np.int64); poff[:] = piv_off
-    ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw)
-    dt = (time.perf_counter() - t0) / steps
-    nbytes = pxy.nbytes + puv.nbytes + poff.nbytes + 12 * xy.shape[0]
-    return {"value": xy.shape[0] / dt, "ms_per_step": dt * 1e3, "steps": steps, "bytes_over_pcie_per_step": int(nbytes),
-            "what": "upload xyuvav + pivot CSR, bounds check, kernel, download [N][3]; pair resident"}
+
+    def run(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        return (time.perf_counter() - t0) / steps, out
+
+    dt_geo, got = run(lambda: ctx.matching_ncc_dlc_geo(pxy, case.offset, case.dt, case.mpp, case.ocw))
+    dt_csr, _ = run(lambda: ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw))
+    same = bool(np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)))
+    return {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3, "steps": steps,
+            "bytes_over_pcie_per_step": int(pxy.nbytes + api.CORRIDOR_BYTES * n + 24 + 12 * n),
+            "identical_to_resident_run": same,
+            "what": "host corridors (libm, threaded) + upload xyuvav and 24 B/point + device pivot lists + bounds check + kernel + download [N][3]; pair resident",
+            "csr_upload_form": {"value": n / dt_csr, "ms_per_step": dt_csr * 1e3,
+                                "bytes_over_pcie_per_step": int(pxy.nbytes + puv.nbytes + poff.nbytes + 12 * n)}}
 
 
 def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, cpu):
@@ -360,8 +395,13 @@ def qm_leg(torch, api, synth, ctx, dev, case, sweeps, check, reps=5):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
     ms = float(np.median(times[1:]))
-    out = {"sweeps_cap": sweeps, "sweeps_run": int(d_sw.item()), "grid": [dimy, dimx], "neighbours": int(ruv.shape[0]),
+    nsw = int(d_sw.item())
+    out = {"sweeps_cap": sweeps, "sweeps_run": nsw, "grid": [dimy, dimx], "neighbours": int(ruv.shape[0]),
            "ms": ms, "grid_points_per_s": dimx * dimy / (ms * 1e-3),
+           "sweeps_per_s": max(nsw, 1) / (ms * 1e-3), "launches_per_sweep": api.qm_launches_per_sweep(),
+           "launches_enqueued": 1 + sweeps * api.qm_launches_per_sweep(),
+           "bound": "latency: per sweep one f64 fit kernel (<= 81 neighbour gathers + 6x6 Gauss-Jordan per investigated point, "
+                    "thread per point) + one commit/compare/decide launch; the data (~1.4 KB per investigated point) is L2-resident",
            "investigated_frac_initial": float((mvn[np.arange(dimx * dimy), dpf.reshape(-1), 4] < 0.6).mean())}
     if check:
         from oracle import oracle as orc

@@ -34,7 +34,19 @@
 #define MIMC3_XY_ACC 2          // independent dot4 chains of the sxy-only body (tuning switch)
 #endif
 #ifndef MIMC3_SAT_DEFER
-#define MIMC3_SAT_DEFER 1       // table look-ups of a batch: keep the four corners in registers, combine them in the finish
+#define MIMC3_SAT_DEFER 0       // table look-ups of a batch: keep the four corners in registers, combine them in the finish (measured: the
+#endif                          // eight registers cost more in spills than the early wait, 3.26 vs 3.13 ms)
+#ifndef MIMC3_OPQ_SMALL
+#define MIMC3_OPQ_SMALL 0       // keep the chip-derived masks of the small chips out of registers too
+#endif
+#ifndef MIMC3_STAGE_KB
+#define MIMC3_STAGE_KB 8        // window rows a thread fetches before it uses any
+#endif
+#ifndef MIMC3_EVEN_PITCH
+#define MIMC3_EVEN_PITCH 0      // LDS window pitch not forced to an odd number of dwords
+#endif
+#ifndef MIMC3_FAST_BATCH
+#define MIMC3_FAST_BATCH 64     // table cells of a one-wave config finished per pass (their slots hold one word)
 #endif
 
 namespace mimc3 {
@@ -410,7 +422,7 @@ struct PxCfg {
     static constexpr uint32_t LASTFF = P::lowmask_c(LASTN);
     static constexpr uint32_t LAST01 = LASTFF & 0x01010101u;
     static constexpr int CPR = 64 / LPC;                     // cells per evaluation round
-    static constexpr bool OPQ = LPC_ >= 64;                  // big chips: keep chip-derived masks out of registers (see PxU8::task)
+    static constexpr bool OPQ = LPC_ >= 64 || MIMC3_OPQ_SMALL;   // big chips: keep chip-derived masks out of registers (see PxU8::task)
     // Big chips with exact integer sums: a cell whose box (or whose chip) holds null pixels is evaluated as the FAST body
     // (3 dot products per dword) plus CORRECTIONS summed over short lists of the null pixels -- window nulls take chip
     // values out of n, sx, sxx; chip nulls take window values out of sy, syy -- instead of the six-sum GENERAL body
@@ -803,7 +815,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const uint32_t keep = col_keep(c);
             const int x0 = P::G * c - pt.sh;                              // window column of the dword's first pixel
             bool hit = false;                                             // this column holds excluded pixels (x range of the null box)
-            constexpr int KB = 8;
+            constexpr int KB = MIMC3_STAGE_KB;
             auto batch = [&](auto tail_c, auto nonull_c, int rb) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail_c)::value;
                 constexpr bool NONULL = decltype(nonull_c)::value;       // the table says the written area holds no null: plain copy
@@ -1166,8 +1178,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 for (int k = 0; k < 2; k++) if (l + k * C::LPC < nLc) ec[k] = Lc[l + k * C::LPC];
             }
         }
-        for (int b0 = 0; b0 < cnt; b0 += kSumBatch) {
-            const int nb = (cnt - b0) < kSumBatch ? (cnt - b0) : kSumBatch;
+        // table cells of the one-wave configs park ONE word (sxy): 64 of them fit where 32 six-word slots do, and the f64 finish
+        // then runs on all 64 lanes
+        const bool one_word = P::SAT && !kAPark && NT == 64 && mode == M_FAST && MIMC3_FAST_BATCH > kSumBatch;
+        const int batch_cells = one_word ? MIMC3_FAST_BATCH : kSumBatch;
+        for (int b0 = 0; b0 < cnt; b0 += batch_cells) {
+            const int nb = (cnt - b0) < batch_cells ? (cnt - b0) : batch_cells;
             // thread t finishes cell b0 + t of this batch: its window-side box sums (sum b, sum b^2) come from the table -- four
             // loads issued now, consumed after the evaluation rounds below
             // (the four corners stay in registers until the finish: combining them here would wait for the loads right away)
@@ -1286,7 +1302,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                 } else {
                     if (P::SAT && mode == M_FAST) {
-                        if (on && l == 0) sp[5] = P::bits(acc.sxy);     // the other five sums are the point's constants and the table's
+                        if (on && l == 0) { if (one_word) sums[slot] = P::bits(acc.sxy); else sp[5] = P::bits(acc.sxy); }   // the other five sums are the point's constants and the table's
                     } else {
                         if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
                         if (on && l == 0) {
@@ -1301,7 +1317,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const uint32_t pk = ids[dir * (b0 + tid)];
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 Store *sp = sums + 6 * tid;
-                Store v[6] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
+                Store v[6] = {0, 0, 0, 0, 0, 0};
+                if (one_word) v[5] = sums[tid];
+                else { v[0] = sp[0]; v[1] = sp[1]; v[2] = sp[2]; v[3] = sp[3]; v[4] = sp[4]; v[5] = sp[5]; }
                 if constexpr (kAPark) {
                     // cells whose n, sx, sxx are the point's constants (minus the corrections that were added above)
                     const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)));
@@ -1765,7 +1783,7 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     const int csx = Dx2 - 2 * C::OCW + 1;
     constexpr int G = C::P::G, LG = C::P::LOG2G;
     const int pw_a = ((G - 1 + (Dx2 - 1) + (full ? 1 : 0) + G - 1) >> LG) + 1, pw_b = ((G - 1 + csx - 2) >> LG) + C::GPR + 1;
-    r.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | 1);   // odd dword pitch: lanes that own consecutive rows hit distinct banks
+    r.lds_pw = 4 * ((pw_a > pw_b ? pw_a : pw_b) | (MIMC3_EVEN_PITCH ? 0 : 1));   // odd dword pitch: lanes that own consecutive rows hit distinct banks
     // NCC cache slots per point: the certain set (<= 9 per pivot) + room for the climbs; long corridors
     // (many pivots) climb further.  Points that still overflow are redone by the general kernel.
     static const int slack_env = getenv("MIMC3_U8_CACHE_SLACK") ? atoi(getenv("MIMC3_U8_CACHE_SLACK")) : 0;   // tests shrink it to force the overflow path
