@@ -63,6 +63,7 @@ struct mimc3_ctx {
     int32_t H = 0, W = 0;
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
     DevBuf sat0, sat1, sat_tmp;         // packed summed-area tables of pl0 / pl1 (sum b | sum b^2 | nulls; sat_kernel.hip), built with the planes
+    DevBuf hsat0, hsat1, hsz0, hsz1;    // the same for the u16 planes hpl0 / hpl1: sum q | sum q^2, and the null counts
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
     DevBuf fail;                        // [0] count, [1..] points the offset-u8 kernel handed to the u16 kernel
     bool u8o_ok = false;                // integer (shift 0) u16 planes whose local range mostly fits 8 bits: try PxU8o first
@@ -278,6 +279,22 @@ static int build_u8_tables(mimc3_ctx *c)
     return 0;
 }
 
+// ... and of the u16 planes (enqueued on `s`; callers order later use on other streams themselves)
+static int build_u16_tables(mimc3_ctx *c, hipStream_t s)
+{
+    const int Hp = c->H + 2 * mimc3::kU8Pad;
+    HIP_TRY(c->hsat0.reserve(mimc3::sat_bytes(Hp, c->Wp)));
+    HIP_TRY(c->hsat1.reserve(mimc3::sat_bytes(Hp, c->Wp)));
+    HIP_TRY(c->hsz0.reserve(mimc3::sat_null_bytes(Hp, c->Wp)));
+    HIP_TRY(c->hsz1.reserve(mimc3::sat_null_bytes(Hp, c->Wp)));
+    HIP_TRY(c->sat_tmp.reserve(mimc3::sat_scratch_bytes(Hp, c->Wp)));
+    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl0.p), Hp, c->Wp, static_cast<unsigned long long *>(c->hsat0.p),
+                                  static_cast<unsigned int *>(c->hsz0.p), c->sat_tmp.p, s));
+    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl1.p), Hp, c->Wp, static_cast<unsigned long long *>(c->hsat1.p),
+                                  static_cast<unsigned int *>(c->hsz1.p), c->sat_tmp.p, s));
+    return 0;
+}
+
 static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
 {
     c->u8_ok = false;
@@ -327,6 +344,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
             HIP_TRY(hipMemsetAsync(c->hpl1.p, 0, hb, c->stream));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i0, c->H, c->W, static_cast<unsigned short *>(c->hpl0.p), c->Wp, pad, s0, c->stream));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, pad, s1, c->stream));
+            RC_TRY(build_u16_tables(c, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->shift0 = s0; c->shift1 = s1; c->u16_ok = true; c->hpl_valid = true;
             // 9-bit integers (gradients of 8-bit images): does the LOCAL range fit 8 bits almost everywhere?  Then the
@@ -526,6 +544,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
             HIP_TRY(hipMemsetAsync(c->hpl1.p, 0, hb, s));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i0, c->H, c->W, static_cast<unsigned short *>(c->hpl0.p), c->Wp, mimc3::kU8Pad, 0, s));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, mimc3::kU8Pad, 0, s));
+            RC_TRY(build_u16_tables(c, s));
             c->shift0 = c->shift1 = 0;
             c->hpl_valid = true;
         }
@@ -555,6 +574,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         } else if (want_u16) {
             u.p0 = static_cast<const unsigned char *>(c->hpl0.p); u.p1 = static_cast<const unsigned char *>(c->hpl1.p);
             u.scale0 = 1.0 / (double)(1 << c->shift0); u.scale1 = 1.0 / (double)(1 << c->shift1);
+            u.sat0 = c->hsat0.p; u.sat1 = c->hsat1.p; u.satz0 = c->hsz0.p; u.satz1 = c->hsz1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
             if (c->u8o_ok && c->u16_ok && c->path_mode == 0) {
                 // u8 machinery through per-point offsets first; what does not fit is redone by the u16 kernel in list mode
                 HIP_TRY(failb.reserve(sizeof(int32_t) * ((size_t)N + 1)));

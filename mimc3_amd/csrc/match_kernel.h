@@ -62,6 +62,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t rt_tw;                                  // tiles per plane row
     // packed summed-area tables of the two planes (sat_kernel.hip; policies with P::SAT), (Hp + 1) rows of sat_ws entries
     const void *sat0, *sat1;
+    const void *satz0, *satz1;      // u16 planes: null counts (u32), same geometry
     int32_t sat_ws;
     int32_t lookahead;              // speculative climb: 3x3 blocks requested ahead along a straight move
     unsigned long long *stats;     // diagnostics only (env MIMC3_U8_STATS): per-phase s_memtime sums

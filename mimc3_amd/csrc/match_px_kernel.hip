@@ -123,10 +123,15 @@ struct PxU8 {
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = true;                     // exact integer sums: null corrections may be applied in any order
     static constexpr bool SAT = true;                         // the planes come with a packed summed-area table (sum b | sum b^2 | nulls)
+    static constexpr bool SATZ = false;                       // ... whose null counts live in a second table (u16 planes)
+    static constexpr bool SAT_CHIP = true;                    // the chip's sums and null count are table look-ups too
     typedef unsigned long long SatT;
-    __device__ static __forceinline__ uint32_t sat_s(SatT q) { return (uint32_t)q & ((1u << kSatSqShift8) - 1u); }
-    __device__ static __forceinline__ uint32_t sat_ss(SatT q) { return (uint32_t)(q >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u); }
+    __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return (uint32_t)q & ((1u << kSatSqShift8) - 1u); }
+    __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return (uint32_t)(q >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u); }
     __device__ static __forceinline__ int sat_nulls(SatT q) { return (int)(q >> kSatNullShift8); }
+    // window-side sums of a box from its table entry, in the units the kernel accumulates in (z = nulls in the box, k = the
+    // window offset of the per-point-offset policy, npx = pixels of the box)
+    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *p; }
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -218,11 +223,14 @@ struct PxU16 {
     static constexpr int BPP = 2, G = 2, LOG2G = 1;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = true;
-    static constexpr bool SAT = false;
+    static constexpr bool SAT = true;                         // sum q | sum q^2 << 25 in one table, null counts in a second one
+    static constexpr bool SATZ = true;
+    static constexpr bool SAT_CHIP = true;
     typedef unsigned long long SatT;
-    __device__ static __forceinline__ uint32_t sat_s(SatT) { return 0u; }
-    __device__ static __forceinline__ uint32_t sat_ss(SatT) { return 0u; }
+    __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
+    __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
+    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const unsigned short *>(p); }
     typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
@@ -239,6 +247,10 @@ struct PxU16 {
     template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t a, uint32_t, uint32_t padff, bool static_pad, uint32_t bw, float)
     {
+        if (MODE == M_XY) {                                         // (see PxU8::task)
+            if (static_pad) acc.sxy = dot2(a, bw, (uint32_t)acc.sxy); else acc.sy = dot2(a, bw, (uint32_t)acc.sy);
+            return;
+        }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a)); // see PxU8::task: keeps the masks out of registers
         const uint32_t mf = (MODE == M_FAST && static_pad) ? padff : ffff_from8000(nz8000(a));
         if (MODE == M_FAST || MODE == M_CHIPNULL) {
@@ -286,7 +298,21 @@ struct PxU16 {
 //      bit-identical to the u16 path's.  Points that do not fit are handed to the u16 kernel through fail_list. -------
 struct PxU8o : PxU8 {
     static constexpr bool SRC16 = true;
-    static constexpr bool SAT = false;
+    // the u16 planes' tables serve the window side: the true box sums are converted to the kernel's offset units,
+    //   sum (q - k) = sum q - k m,   sum (q - k)^2 = sum q^2 - 2 k sum q + k^2 m,   m = non-null pixels of the box.
+    // The chip side stays as it is (its offset is only known after the range scan, and the sums are taken while staging).
+    static constexpr bool SAT = true;
+    static constexpr bool SATZ = true;
+    static constexpr bool SAT_CHIP = false;
+    __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
+    __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
+    __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
+    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int z, int k, int npx)
+    {
+        const long long m = npx - z, K = k, s1 = (long long)sat_s(q), s2 = (long long)sat_ss(q);
+        sy = (unsigned long long)(s1 - K * m);
+        syy = (unsigned long long)(s2 - 2 * K * s1 + K * K * m);
+    }
     __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb, int ka, int kb)
     {
         const long long n = sp[0], sx_ = sp[1], sy_ = sp[2], sxx_ = sp[3], syy_ = sp[4], sxy_ = sp[5];
@@ -338,11 +364,12 @@ struct PxF32 {
     static constexpr int BPP = 4, G = 1, LOG2G = 0;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = false;
-    static constexpr bool SAT = false;
+    static constexpr bool SAT = false, SATZ = false, SAT_CHIP = false;
     typedef unsigned long long SatT;
-    __device__ static __forceinline__ uint32_t sat_s(SatT) { return 0u; }
-    __device__ static __forceinline__ uint32_t sat_ss(SatT) { return 0u; }
+    __device__ static __forceinline__ unsigned long long sat_s(SatT) { return 0u; }
+    __device__ static __forceinline__ unsigned long long sat_ss(SatT) { return 0u; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
+    __device__ static __forceinline__ void sat_win_sums(unsigned long long &, unsigned long long &, SatT, int, int, int) {}
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const uint32_t *>(p); }
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -564,7 +591,10 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
 }
 
 static constexpr int kStatW = 16;      // diagnostics: 8 phase clocks + cell counts (clean, dirty, evaluate calls) + null-list use
-static constexpr int kSumBatch = 32;   // cells whose reduced sums are parked in LDS before the f64 finish
+#ifndef MIMC3_SUM_BATCH
+#define MIMC3_SUM_BATCH 32
+#endif
+static constexpr int kSumBatch = MIMC3_SUM_BATCH;   // cells whose reduced sums are parked in LDS before the f64 finish
 
 #define MIMC3_STAMP(i)                                                                         \
     if (p.stats) {                                                                             \
@@ -629,14 +659,23 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // window's written area -- two box queries, issued here so that they are in flight while LDS is cleared
     typedef typename P::SatT SatT;
     const SatT *sat_chip = nullptr, *sat_win = nullptr;
-    SatT chipQ = 0, winQ = 0;
+    const uint32_t *satz_win = nullptr;
+    SatT chipQ = 0;
+    int chip_nulls = 0, win_nulls = 0;
     if constexpr (P::SAT) {
         sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
         sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
-        chipQ = sat_box(sat_chip, p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
-        winQ = sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * pt.dx2 + (full_win ? 1 : 0), 2 * pt.dy2 + (full_win ? 1 : 0));   // the written area (:869-886)
+        satz_win = reinterpret_cast<const uint32_t *>(p.swap ? p.satz0 : p.satz1);
+        const int wc = 2 * pt.dx2 + (full_win ? 1 : 0), wr = 2 * pt.dy2 + (full_win ? 1 : 0);          // the written area (:869-886)
+        if constexpr (P::SATZ) win_nulls = (int)sat_box(satz_win, p.sat_ws, wu0, wv0, wc, wr);
+        else win_nulls = P::sat_nulls(sat_box(sat_win, p.sat_ws, wu0, wv0, wc, wr));
+        if constexpr (P::SAT_CHIP) {
+            chipQ = sat_box(sat_chip, p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
+            if constexpr (P::SATZ) chip_nulls = (int)sat_box(reinterpret_cast<const uint32_t *>(p.swap ? p.satz1 : p.satz0), p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
+            else chip_nulls = P::sat_nulls(chipQ);
+        }
     }
-    (void)sat_chip; (void)sat_win; (void)chipQ; (void)winQ;
+    (void)sat_chip; (void)sat_win; (void)satz_win; (void)chipQ; (void)chip_nulls; (void)win_nulls;
 
     // ---- LDS carve ------------------------------------------------------------------------------
     unsigned char *W = smem;                                              // [Dy2][PW]
@@ -865,7 +904,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             };
             int rb = r0;
-            if (P::SAT && P::sat_nulls(winQ) == 0) {
+            if (P::SAT && win_nulls == 0) {
                 for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, std::true_type{}, rb);
                 if (rb < wrows) batch(std::true_type{}, std::true_type{}, rb);
             } else {
@@ -934,11 +973,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
                 const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
                 a &= pff;
-                if constexpr (P::SAT) { }                                                            // counts and sums come from the table
+                if constexpr (P::SAT_CHIP) { }                                                       // counts and sums come from the table
                 else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);    // the exact counts are taken afterwards, and only then
                 else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
                 A[i][j] = a;
-                if constexpr (!P::SAT) P::chip_acc(SX, SXX, a);
+                if constexpr (!P::SAT_CHIP) P::chip_acc(SX, SXX, a);
                 if constexpr (C::SPARSE) {
                     if ((j % NW) == wave && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;   // every wave holds the whole chip: each writes a share of the copy
                 }
@@ -953,19 +992,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             uint32_t a = (P::G > 1) ? alignb(chip_dword(rr, j + (P::G > 1 ? 1 : 0)), g0, sa) : g0;
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
-            if constexpr (P::SAT) { }
+            if constexpr (P::SAT_CHIP) { }
             else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);
             else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
             if (C::FULLTAIL && on && j == GPR - 1) padoff = toff[k];
-            if constexpr (!P::SAT) P::chip_acc(SX, SXX, a);
+            if constexpr (!P::SAT_CHIP) P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
                 if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
             }
         }
         // (with a table the chip's null count is known: only the sparse-correction configs look at the pixels again, to LIST them)
-        if constexpr (P::SAT) chip_susp = C::SPARSE && P::sat_nulls(chipQ) != 0;
+        if constexpr (P::SAT_CHIP) chip_susp = C::SPARSE && chip_nulls != 0;
         if (P::INTEGER && chip_susp) {                        // rare: the lane's chip dwords again, counted exactly (and listed)
 #pragma unroll
             for (int i = 0; i < C::RF; i++) {
@@ -1019,8 +1058,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             }
         }
-        if constexpr (P::SAT) {
-            bad_chip = exc_chip = P::sat_nulls(chipQ);       // null <=> DN == 0 for integral DN: both counts (:622, :723)
+        if constexpr (P::SAT_CHIP) {
+            bad_chip = exc_chip = chip_nulls;                // null <=> DN == 0 for integral DN: both counts (:622, :723)
             SX = (Sum)P::sat_s(chipQ); SXX = (Sum)P::sat_ss(chipQ);
         } else {
             bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
@@ -1180,14 +1219,16 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         }
         // table cells of the one-wave configs park ONE word (sxy): 64 of them fit where 32 six-word slots do, and the f64 finish
         // then runs on all 64 lanes
-        const bool one_word = P::SAT && !kAPark && NT == 64 && mode == M_FAST && MIMC3_FAST_BATCH > kSumBatch;
-        const int batch_cells = one_word ? MIMC3_FAST_BATCH : kSumBatch;
+        constexpr int kFastBatch = (6 * kSumBatch < MIMC3_FAST_BATCH) ? 6 * kSumBatch : MIMC3_FAST_BATCH;
+        const bool one_word = P::SAT && !kAPark && NT == 64 && mode == M_FAST && kFastBatch > kSumBatch;
+        const int batch_cells = one_word ? kFastBatch : kSumBatch;
         for (int b0 = 0; b0 < cnt; b0 += batch_cells) {
             const int nb = (cnt - b0) < batch_cells ? (cnt - b0) : batch_cells;
             // thread t finishes cell b0 + t of this batch: its window-side box sums (sum b, sum b^2) come from the table -- four
             // loads issued now, consumed after the evaluation rounds below
             // (the four corners stay in registers until the finish: combining them here would wait for the loads right away)
             [[maybe_unused]] SatT cellQ = 0, q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+            [[maybe_unused]] int cellZ = 0;
             if constexpr (P::SAT) {
                 const bool need = mode == M_FAST || (C::SPARSE && sparse_on);
                 if (need && tid < nb) {
@@ -1195,6 +1236,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const SatT *r0 = sat_win + (size_t)(wv0 + (int)((pk >> 8) & 0xffu)) * p.sat_ws + (wu0 + (int)(pk & 0xffu)), *r1 = r0 + (size_t)CW * p.sat_ws;
                     q00 = r0[0]; q01 = r0[CW]; q10 = r1[0]; q11 = r1[CW];
                     if (!MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
+                    if constexpr (P::SRC16) {       // offset units: the conversion needs the nulls of a dirty box (its unmasked sums count them as 0, not as -k)
+                        if (dirty_list) cellZ = (int)sat_box(satz_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
+                    }
                 }
             }
             for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
@@ -1328,14 +1372,22 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         // window-side sums from the table: every cell but the dense ones and the masked CHIPNULL bodies of the
                         // configs without null lists (those accumulated sy, syy themselves)
                         const bool sparse_cell = C::SPARSE && sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2));
-                        if (sparse_cell || mode == M_FAST) { v[2] += (Store)P::sat_s(cellQ); v[4] += (Store)P::sat_ss(cellQ); }
+                        if (sparse_cell || mode == M_FAST) {
+                            unsigned long long ty = 0, tyy = 0;
+                            P::sat_win_sums(ty, tyy, cellQ, cellZ, kb, C::NPX);
+                            v[2] += (Store)ty; v[4] += (Store)tyy;
+                        }
                     }
                     if (C::SPARSE) v[0] = (Store)(uint32_t)v[0];          // n travels as a 32-bit count (corrections wrap modulo 2^32)
 #pragma unroll
                     for (int k = 0; k < 6; k++) sp[k] = 0;                 // the slot is empty for the next batch
                 }
                 if constexpr (P::SAT && !kAPark) {
-                    if (mode == M_FAST) { v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = (Store)P::sat_s(cellQ); v[3] = P::bits(SXX); v[4] = (Store)P::sat_ss(cellQ); }
+                    if (mode == M_FAST) {
+                        unsigned long long ty = 0, tyy = 0;
+                        P::sat_win_sums(ty, tyy, cellQ, 0, kb, C::NPX);
+                        v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = (Store)ty; v[3] = P::bits(SXX); v[4] = (Store)tyy;
+                    }
                 }
                 *vslot(cx, cy) = P::ncc(v, sc_chip, sc_win, ka, kb);
             }

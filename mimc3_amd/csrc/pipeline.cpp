@@ -237,7 +237,7 @@ int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t 
         if (u0 - ocw_max < 0 || u0 + ocw_max >= W || v0 - ocw_max < 0 || v0 + ocw_max >= H)
             return mimc3::fail(MIMC3_EBOUNDS, "mimc3_vmap: a grid point's chip leaves the image (u=" + std::to_string(u0) + ", v=" + std::to_string(v0) + ")");
     }
-    const size_t n = (size_t)ns;
+    (void)ns;
     void *d_xy = nullptr;
     d_xy = hp[0].d_xy;                                        // uploaded with the corridors (vmap_host_pivots)
     if (!d_xy) return mimc3::fail(MIMC3_ESTATE, "mimc3_vmap: pivots were not made");
