@@ -580,7 +580,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
         }
         else P::template task<MODE, C::OPQ>(acc, av, 0, 0, false, bw, pt.thr);   // tail tasks: pad/null masks come from the chip dword itself
     }
-    if constexpr (MODE == M_XY && MIMC3_XY_ACC >= 2 && !C::CHIP_LDS) { acc.sxy += acc.sy - sy_in; acc.sy = sy_in; }   // fold the second chain (sy carried the caller's corrections in)
+    if constexpr (MODE == M_XY && MIMC3_XY_ACC >= 2) { acc.sxy += acc.sy - sy_in; acc.sy = sy_in; }   // fold the second chain (sy carried the caller's corrections in)
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE != M_XY) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
