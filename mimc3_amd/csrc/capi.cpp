@@ -74,6 +74,8 @@ struct mimc3_ctx {
     int shift0 = 0, shift1 = 0;
     DevBuf fpl0, fpl1;                  // zero-bordered f32 planes (register-tiled f32 kernel), built on first use
     bool fplanes_ok = false;
+    DevBuf fsat0, fsat1;                // their 16-byte summed-area tables when every pixel is an integer in [0, 2^18) (16-bit DN)
+    bool f32i_ok = false;
     int32_t Wp = 0;
     bool u8_ok = false;                 // both images proven to be integers in [0,255]
     int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
@@ -492,6 +494,27 @@ static int build_f32_planes(mimc3_ctx *c, hipStream_t s)
     HIP_TRY(mimc3::launch_prep_f32(c->d_i0, c->H, c->W, static_cast<float *>(c->fpl0.p), c->Wp, mimc3::kU8Pad, s));
     HIP_TRY(mimc3::launch_prep_f32(c->d_i1, c->H, c->W, static_cast<float *>(c->fpl1.p), c->Wp, mimc3::kU8Pad, s));
     c->fplanes_ok = true;
+    // 16-bit DN (every pixel an integer in [0, 2^18)): the f64 sums of the reference are exact integers in any order, and the
+    // planes get summed-area tables like the integer planes (one read-back per image pair)
+    c->f32i_ok = false;
+    if (!getenv("MIMC3_NO_F32_TABLES")) {
+        int not_int = 1;
+        HIP_TRY(c->flag.reserve(sizeof(int)));
+        HIP_TRY(hipMemsetAsync(c->flag.p, 0, sizeof(int), s));
+        HIP_TRY(mimc3::launch_detect_int16(c->d_i0, (size_t)c->H * c->W, static_cast<int *>(c->flag.p), s));
+        HIP_TRY(mimc3::launch_detect_int16(c->d_i1, (size_t)c->H * c->W, static_cast<int *>(c->flag.p), s));
+        HIP_TRY(hipMemcpyAsync(&not_int, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!not_int) {
+            const int Hp = c->H + 2 * mimc3::kU8Pad;
+            HIP_TRY(c->fsat0.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
+            HIP_TRY(c->fsat1.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
+            HIP_TRY(c->sat_tmp.reserve(mimc3::sat2_scratch_bytes(Hp, c->Wp)));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl0.p), Hp, c->Wp, static_cast<mimc3::Sat2 *>(c->fsat0.p), c->sat_tmp.p, s));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl1.p), Hp, c->Wp, static_cast<mimc3::Sat2 *>(c->fsat1.p), c->sat_tmp.p, s));
+            c->f32i_ok = true;
+        }
+    }
     return 0;
 }
 
@@ -597,6 +620,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         } else {
             RC_TRY(build_f32_planes(c, s));
             u.p0 = static_cast<const unsigned char *>(c->fpl0.p); u.p1 = static_cast<const unsigned char *>(c->fpl1.p);
+            if (c->f32i_ok) { u.sat0 = c->fsat0.p; u.sat1 = c->fsat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp); }
             e = mimc3::launch_match_f32x(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 2;
         }

@@ -131,7 +131,7 @@ struct PxU8 {
     __device__ static __forceinline__ int sat_nulls(SatT q) { return (int)(q >> kSatNullShift8); }
     // window-side sums of a box from its table entry, in the units the kernel accumulates in (z = nulls in the box, k = the
     // window offset of the per-point-offset policy, npx = pixels of the box)
-    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
+    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int, int, int) { sy = (uint32_t)sat_s(q); syy = (uint32_t)sat_ss(q); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *p; }
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -307,11 +307,11 @@ struct PxU8o : PxU8 {
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
-    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int z, int k, int npx)
+    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int z, int k, int npx)
     {
         const long long m = npx - z, K = k, s1 = (long long)sat_s(q), s2 = (long long)sat_ss(q);
-        sy = (unsigned long long)(s1 - K * m);
-        syy = (unsigned long long)(s2 - 2 * K * s1 + K * K * m);
+        sy = (uint32_t)(s1 - K * m);                                // sums of bytes / squared bytes over <= 81^2 pixels: < 2^32
+        syy = (uint32_t)(s2 - 2 * K * s1 + K * K * m);
     }
     __device__ static __forceinline__ float ncc(const Store *sp, double sa, double sb, int ka, int kb)
     {
@@ -369,7 +369,7 @@ struct PxF32 {
     __device__ static __forceinline__ unsigned long long sat_s(SatT) { return 0u; }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT) { return 0u; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
-    __device__ static __forceinline__ void sat_win_sums(unsigned long long &, unsigned long long &, SatT, int, int, int) {}
+    __device__ static __forceinline__ void sat_win_sums(double &, double &, SatT, int, int, int) {}
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const uint32_t *>(p); }
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -427,6 +427,30 @@ struct PxF32 {
         const double num = dn * sxy - sx * sy;
         const double den = sqrt((dn * sxx - sx * sx) * (dn * syy - sy * sy));
         return (float)(num / den);
+    }
+};
+
+// ---- pixel policy: f32 planes whose pixels are all INTEGERS in [0, 2^18) (16-bit DN and the integer gradients of such images).  The reference's arithmetic is the
+//      f32 policy's -- f32 products that round above 2^24 (T1), f64 sums -- but every term is an integer below 2^36 and every
+//      sum an integer below 2^53: exact in any order, so the window-side sums of a null-free box (sum b, sum fl(b b)) and the
+//      chip's (sum a, sum fl(a a), nulls) are box queries of a 16-byte summed-area table (sat_kernel.hip) and the evaluation
+//      of such a box keeps ONE product stream, sxy = sum fl(a b), instead of three. -------------------------------------------
+struct PxF32i : PxF32 {
+    static constexpr bool SAT = true, SATZ = false, SAT_CHIP = true;
+    typedef Sat2 SatT;
+    __device__ static __forceinline__ double sat_s(const SatT &q) { return (double)(q.a & ((1ull << kSatNullShiftF) - 1ull)); }
+    __device__ static __forceinline__ double sat_ss(const SatT &q) { return (double)q.b; }
+    __device__ static __forceinline__ int sat_nulls(const SatT &q) { return (int)(q.a >> kSatNullShiftF); }
+    __device__ static __forceinline__ void sat_win_sums(double &sy, double &syy, const SatT &q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
+    template <int MODE, bool OPQ>
+    __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t p01, uint32_t pff, bool static_pad, uint32_t bu, float thr)
+    {
+        if (MODE == M_XY) {                                         // (see PxU8::task: `static_pad` picks one of two independent chains)
+            const double pr = (double)(__uint_as_float(au) * __uint_as_float(bu));
+            if (static_pad) acc.sxy += pr; else acc.sy += pr;
+            return;
+        }
+        PxF32::template task<MODE, OPQ>(acc, au, p01, pff, static_pad, bu, thr);
     }
 };
 
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     typedef typename P::SatT SatT;
     const SatT *sat_chip = nullptr, *sat_win = nullptr;
     const uint32_t *satz_win = nullptr;
-    SatT chipQ = 0;
+    SatT chipQ{};
     int chip_nulls = 0, win_nulls = 0;
     if constexpr (P::SAT) {
         sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
@@ -1227,7 +1251,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // thread t finishes cell b0 + t of this batch: its window-side box sums (sum b, sum b^2) come from the table -- four
             // loads issued now, consumed after the evaluation rounds below
             // (the four corners stay in registers until the finish: combining them here would wait for the loads right away)
-            [[maybe_unused]] SatT cellQ = 0, q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+            [[maybe_unused]] SatT cellQ{}, q00{}, q01{}, q10{}, q11{};
             [[maybe_unused]] int cellZ = 0;
             if constexpr (P::SAT) {
                 const bool need = mode == M_FAST || (C::SPARSE && sparse_on);
@@ -1373,9 +1397,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         // configs without null lists (those accumulated sy, syy themselves)
                         const bool sparse_cell = C::SPARSE && sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2));
                         if (sparse_cell || mode == M_FAST) {
-                            unsigned long long ty = 0, tyy = 0;
+                            Sum ty = 0, tyy = 0;
                             P::sat_win_sums(ty, tyy, cellQ, cellZ, kb, C::NPX);
-                            v[2] += (Store)ty; v[4] += (Store)tyy;
+                            v[2] += P::bits(ty); v[4] += P::bits(tyy);
                         }
                     }
                     if (C::SPARSE) v[0] = (Store)(uint32_t)v[0];          // n travels as a 32-bit count (corrections wrap modulo 2^32)
@@ -1384,9 +1408,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
                 if constexpr (P::SAT && !kAPark) {
                     if (mode == M_FAST) {
-                        unsigned long long ty = 0, tyy = 0;
+                        Sum ty = 0, tyy = 0;
                         P::sat_win_sums(ty, tyy, cellQ, 0, kb, C::NPX);
-                        v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = (Store)ty; v[3] = P::bits(SXX); v[4] = (Store)tyy;
+                        v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = P::bits(ty); v[3] = P::bits(SXX); v[4] = P::bits(tyy);
                     }
                 }
                 *vslot(cx, cy) = P::ncc(v, sc_chip, sc_win, ka, kb);
@@ -1942,6 +1966,16 @@ bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
 hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
+    if (a.sat0 && a.sat1) {        // integral 16-bit DN: the planes come with summed-area tables
+        switch (a.ocw) {
+        case 7: return launch_cfg<PxCfg<PxF32i, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 15: return launch_cfg<PxCfg<PxF32i, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 16: return launch_cfg<PxCfg<PxF32i, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 30: return launch_cfg<PxCfg<PxF32i, 30, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 40: return launch_cfg<PxCfg<PxF32i, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.ocw) {
     case 7: return launch_cfg<PxCfg<PxF32, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);

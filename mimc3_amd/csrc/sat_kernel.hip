@@ -39,6 +39,16 @@ template <> struct SatF<unsigned short> {
     }
 };
 
+template <> struct SatF<float> {
+    __device__ static __forceinline__ Sat2 f(float v)
+    {
+        const float sq = v * v;                                      // the reference's f32 product (rounds above 2^24)
+        return Sat2{(unsigned long long)v + ((unsigned long long)(v == 0.0f) << kSatNullShiftF), (unsigned long long)sq};
+    }
+};
+template <class PX> struct SatE { typedef unsigned long long type; };
+template <> struct SatE<float> { typedef Sat2 type; };
+
 // inclusive scan of a 64-bit value over the 64 lanes of a wave
 __device__ __forceinline__ unsigned long long wave_scan(unsigned long long v, int lane)
 {
@@ -49,28 +59,33 @@ __device__ __forceinline__ unsigned long long wave_scan(unsigned long long v, in
     }
     return v;
 }
+__device__ __forceinline__ Sat2 wave_scan(Sat2 v, int lane) { return Sat2{wave_scan(v.a, lane), wave_scan(v.b, lane)}; }
 
 // ---- pass A: row prefix.  One workgroup per plane row y: S[y+1][x+1] = sum_{x' <= x} f(P[y][x']), S[y+1][0] = 0.
 //      (the column pass then adds the rows up in place)
 template <class PX>
-__global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, int Wp, unsigned long long *__restrict__ S, int Ws,
+__global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, int Wp, typename SatE<PX>::type *__restrict__ S, int Ws,
                                                 unsigned int *__restrict__ Z, int have_z)
 {
-    __shared__ unsigned long long wsum[4], zsum[4];
+    typedef typename SatE<PX>::type E;
+    __shared__ E wsum[4];
+    __shared__ unsigned long long zsum[4];
     const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PX *row = plane + (size_t)y * Wp;
-    unsigned long long *out = S + (size_t)(y + 1) * Ws;
+    E *out = S + (size_t)(y + 1) * Ws;
     unsigned int *zout = have_z ? Z + (size_t)(y + 1) * Ws : nullptr;
-    unsigned long long carry = 0, zcarry = 0;
-    if (tid == 0) { out[0] = 0; if (have_z) zout[0] = 0; }
+    E carry{};
+    unsigned long long zcarry = 0;
+    if (tid == 0) { out[0] = E{}; if (have_z) zout[0] = 0; }
     for (int x0 = 0; x0 < Wp; x0 += 256) {
         const int x = x0 + tid;
-        const unsigned v = x < Wp ? (unsigned)row[x] : 1u;         // (positions past the row end are never stored)
-        unsigned long long s = wave_scan(x < Wp ? SatF<PX>::f(v) : 0ull, lane);
-        unsigned long long z = have_z ? wave_scan((x < Wp && v == 0u) ? 1ull : 0ull, lane) : 0ull;
+        const PX v = x < Wp ? row[x] : (PX)1;                       // (positions past the row end are never stored)
+        E s = wave_scan(x < Wp ? SatF<PX>::f(v) : E{}, lane);
+        unsigned long long z = have_z ? wave_scan((x < Wp && v == (PX)0) ? 1ull : 0ull, lane) : 0ull;
         if (lane == 63) { wsum[wave] = s; zsum[wave] = z; }
         __syncthreads();
-        unsigned long long base = carry, zbase = zcarry, tot = 0, ztot = 0;
+        E base = carry, tot{};
+        unsigned long long zbase = zcarry, ztot = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             if (w < wave) { base += wsum[w]; zbase += zsum[w]; }
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(256) void sat_col_partial(const T *__restrict__ S, 
     const int x = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
     if (x >= Ws) return;
     const int r0 = 1 + sg * seg, r1 = min(rows, r0 + seg);          // rows 1 .. rows-1 carry data (row 0 is the zero row)
-    T acc = 0;
+    T acc{};
     for (int r = r0; r < r1; r++) acc += S[(size_t)r * Ws + x];
     part[(size_t)sg * Ws + x] = acc;
 }
@@ -99,13 +114,13 @@ __global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, 
 {
     const int x = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
     if (x >= Ws) return;
-    T run = 0;
+    T run{};
     for (int s = 0; s < sg; s++) run += part[(size_t)s * Ws + x];
     const int r0 = 1 + sg * seg, r1 = min(rows, r0 + seg);
     for (int r = r0; r < r1; r += 4) {                              // four independent loads in flight
         T v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (r + k < r1) ? S[(size_t)(r + k) * Ws + x] : (T)0;
+        for (int k = 0; k < 4; k++) v[k] = (r + k < r1) ? S[(size_t)(r + k) * Ws + x] : T{};
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (r + k < r1) { run += v[k]; S[(size_t)(r + k) * Ws + x] = run; }
@@ -115,17 +130,18 @@ __global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, 
 constexpr int kSatSeg = 64;
 
 template <class PX>
-hipError_t build(const PX *plane, int Hp, int Wp, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s)
+hipError_t build(const PX *plane, int Hp, int Wp, typename SatE<PX>::type *S, unsigned int *Z, void *scratch, hipStream_t s)
 {
+    typedef typename SatE<PX>::type E;
     const int Ws = sat_pitch(Wp), rows = Hp + 1, nseg = (Hp + kSatSeg - 1) / kSatSeg;
-    hipError_t e = hipMemsetAsync(S, 0, sizeof(unsigned long long) * (size_t)Ws, s);                  // row 0
+    hipError_t e = hipMemsetAsync(S, 0, sizeof(E) * (size_t)Ws, s);                  // row 0
     if (e != hipSuccess) return e;
     if (Z && (e = hipMemsetAsync(Z, 0, sizeof(unsigned int) * (size_t)Ws, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(sat_rows<PX>, dim3(Hp), dim3(256), 0, s, plane, Wp, S, Ws, Z, Z ? 1 : 0);
-    unsigned long long *part = static_cast<unsigned long long *>(scratch);
+    E *part = static_cast<E *>(scratch);
     const dim3 grid((Ws + 255) / 256, nseg);
-    hipLaunchKernelGGL(sat_col_partial<unsigned long long>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
-    hipLaunchKernelGGL(sat_col_apply<unsigned long long>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
+    hipLaunchKernelGGL(sat_col_partial<E>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
+    hipLaunchKernelGGL(sat_col_apply<E>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
     if (Z) {
         unsigned int *zp = reinterpret_cast<unsigned int *>(part + (size_t)nseg * Ws);
         hipLaunchKernelGGL(sat_col_partial<unsigned int>, grid, dim3(256), 0, s, Z, Ws, rows, kSatSeg, zp);
@@ -142,6 +158,28 @@ size_t sat_scratch_bytes(int Hp, int Wp)
 {
     const size_t nseg = (size_t)(Hp + kSatSeg - 1) / kSatSeg;
     return (sizeof(unsigned long long) + sizeof(unsigned int)) * nseg * sat_pitch(Wp);
+}
+
+size_t sat2_bytes(int Hp, int Wp) { return sizeof(Sat2) * (size_t)(Hp + 1) * sat_pitch(Wp); }
+size_t sat2_scratch_bytes(int Hp, int Wp) { return sizeof(Sat2) * ((size_t)(Hp + kSatSeg - 1) / kSatSeg) * sat_pitch(Wp); }
+hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, Sat2 *S, void *scratch, hipStream_t s)
+{
+    return build<float>(plane, Hp, Wp, S, nullptr, scratch, s);
+}
+
+__global__ void detect_int16(const float *img, size_t n, int *flag)
+{
+    int f = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = img[i];
+        if (!(v >= 0.0f && v <= 262143.0f && truncf(v) == v)) f = 1;     // NaN fails every comparison
+    }
+    if (f) atomicOr(flag, 1);
+}
+hipError_t launch_detect_int16(const float *img, size_t n, int *d_flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(detect_int16, dim3(2048), dim3(256), 0, s, img, n, d_flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_sat_u8(const unsigned char *plane, int Hp, int Wp, unsigned long long *S, void *scratch, hipStream_t s)
