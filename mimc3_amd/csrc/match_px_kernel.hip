@@ -36,6 +36,9 @@
 #ifndef MIMC3_SAT_DEFER
 #define MIMC3_SAT_DEFER 0       // table look-ups of a batch: keep the four corners in registers, combine them in the finish (measured: the
 #endif                          // eight registers cost more in spills than the early wait, 3.26 vs 3.13 ms)
+#ifndef MIMC3_WN
+#define MIMC3_WN 1              // window-null cells of a clean chip: three sums + table instead of six
+#endif
 #ifndef MIMC3_OPQ_SMALL
 #define MIMC3_OPQ_SMALL 0       // keep the chip-derived masks of the small chips out of registers too
 #endif
@@ -99,7 +102,9 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 //   GENERAL  the box contains null window pixels                             : all six sums
 //   XY       like FAST, for planes that come with a summed-area table (sat_kernel.hip): the window-side sums sy, syy of a
 //            null-free box are box sums of the IMAGE and are read from the table; only sxy is accumulated here
-enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2, M_XY = 3 };
+//   WN       window nulls in the box, null-free chip, planes with a table: n = pixels - nulls of the box, sy, syy are the
+//            table's (a null is a zero in both sums); sx, sxx (chip pixels over the non-null window pixels) and sxy are accumulated
+enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2, M_XY = 3, M_WN = 4 };
 
 template <class S> struct AccT { uint32_t n; S sx, sy, sxx, syy, sxy; };
 
@@ -156,6 +161,13 @@ struct PxU8 {
         if (MODE == M_XY) {     // pad bytes and nulls are 0 in `a`: no mask at all.  (`static_pad` doubles as the accumulator choice:
             // a single chain of dependent dot4 would stall on its own latency; the caller alternates two and adds them at the end)
             if (static_pad) acc.sxy = dot4(a, bw, acc.sxy); else acc.sy = dot4(a, bw, acc.sy);
+            return;
+        }
+        if (MODE == M_WN) {     // the chip has no null (its pad bytes are 0): only the window's nulls mask
+            const uint32_t t = nz80(bw);
+            acc.sx = dot4(a, t >> 7, acc.sx);
+            acc.sxx = dot4(a & ff_from80(t), a, acc.sxx);
+            acc.sxy = dot4(a, bw, acc.sxy);
             return;
         }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a));
@@ -249,6 +261,13 @@ struct PxU16 {
     {
         if (MODE == M_XY) {                                         // (see PxU8::task)
             if (static_pad) acc.sxy = dot2(a, bw, (uint32_t)acc.sxy); else acc.sy = dot2(a, bw, (uint32_t)acc.sy);
+            return;
+        }
+        if (MODE == M_WN) {
+            const uint32_t t = nz8000(bw);
+            acc.sx = dot2(a, t >> 15, (uint32_t)acc.sx);
+            acc.sxx = dot2(a & ffff_from8000(t), a, (uint32_t)acc.sxx);
+            acc.sxy = dot2(a, bw, (uint32_t)acc.sxy);
             return;
         }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a)); // see PxU8::task: keeps the masks out of registers
@@ -450,6 +469,12 @@ struct PxF32i : PxF32 {
             if (static_pad) acc.sxy += pr; else acc.sy += pr;
             return;
         }
+        if (MODE == M_WN) {                                         // integral DN: a null window pixel is 0.0 (and makes the product 0)
+            const float a = __uint_as_float(au), b = __uint_as_float(bu);
+            const float a2 = (b != 0.0f) ? a : 0.0f;                  // (-0.0 is a null too)
+            acc.sx += (double)a2; acc.sxx += (double)(a2 * a2); acc.sxy += (double)(a * b);
+            return;
+        }
         PxF32::template task<MODE, OPQ>(acc, au, p01, pff, static_pad, bu, thr);
     }
 };
@@ -607,7 +632,8 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
     if constexpr (MODE == M_XY && MIMC3_XY_ACC >= 2) { acc.sxy += acc.sy - sy_in; acc.sy = sy_in; }   // fold the second chain (sy carried the caller's corrections in)
     if (!REDUCE) return acc;                                        // lane-local partial sums (the caller reduces / parks them)
     acc.sxy = P::template gsum<C::LPC>(acc.sxy);
-    if (MODE != M_XY) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
+    if (MODE != M_XY && MODE != M_WN) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
+    if (MODE == M_WN) { acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx); }
     if (MODE == M_GENERAL) {
         acc.n = group_sum<C::LPC>(acc.n); acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx);
     }
@@ -1229,6 +1255,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     constexpr bool kAPark = (C::LPC >= 32) && P::INTEGER;
     auto evaluate = [&](const uint16_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
         const bool dirty_list = (mode == M_GENERAL);
+        // dirty boxes of a null-free chip, planes with a table: the WN body (three sums) instead of the six-sum GENERAL body --
+        // except where a cell of the wave's round touches the never-written last row / column (T4: the table does not know it)
+        const bool wn_ok = P::SAT && MIMC3_WN && dirty_list && exc_chip == 0;
         // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
         uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
         if constexpr (C::SPARSE) {
@@ -1254,13 +1283,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             [[maybe_unused]] SatT cellQ{}, q00{}, q01{}, q10{}, q11{};
             [[maybe_unused]] int cellZ = 0;
             if constexpr (P::SAT) {
-                const bool need = mode == M_FAST || (C::SPARSE && sparse_on);
+                const bool need = mode == M_FAST || (C::SPARSE && sparse_on) || (dirty_list && wn_ok);
                 if (need && tid < nb) {
                     const uint32_t pk = ids[dir * (b0 + tid)];
                     const SatT *r0 = sat_win + (size_t)(wv0 + (int)((pk >> 8) & 0xffu)) * p.sat_ws + (wu0 + (int)(pk & 0xffu)), *r1 = r0 + (size_t)CW * p.sat_ws;
                     q00 = r0[0]; q01 = r0[CW]; q10 = r1[0]; q11 = r1[CW];
                     if (!MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
-                    if constexpr (P::SRC16) {       // offset units: the conversion needs the nulls of a dirty box (its unmasked sums count them as 0, not as -k)
+                    if constexpr (P::SATZ) {        // the nulls of a dirty box: n of a WN cell; the offset policy's unit conversion (its unmasked sums count a null as 0, not as -k)
                         if (dirty_list) cellZ = (int)sat_box(satz_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
                     }
                 }
@@ -1273,6 +1302,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 AccT<Sum> acc;
                 bool six = dirty_list;                                // all six sums are cell-specific (else n, sx, sxx are the point's constants)
                 bool done = false;
+                bool wn_round = false;                                // this wave's cells of the round run the WN body
                 if constexpr (C::SPARSE) {
                     // one wave = one cell.  Unless the box touches the never-written last row/column (T4: a whole row of
                     // nulls) the cell is the FAST body plus corrections over the null lists.
@@ -1350,7 +1380,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 if (!done) {
                     if (mode == M_FAST) acc = eval_round<C, P::SAT ? M_XY : M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
-                    else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    else {
+                        if constexpr (P::SAT) {
+                            const bool t4 = on && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2);
+                            wn_round = wn_ok && __ballot(t4) == 0ull;
+                        }
+                        if (P::SAT && wn_round) acc = eval_round<C, P::SAT ? M_WN : M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                        else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    }
                 }
                 Store *sp = sums + 6 * slot;
                 if constexpr (kAPark) {
@@ -1359,14 +1396,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const Sum rsxy = P::template gsum<16>(acc.sxy);
                     if (lead) atomicAdd(&sp[5], P::bits(rsxy));
                     // sy, syy: the body's sums; with a table only the chip-null corrections of a sparse cell (else the table has it all)
-                    if (!P::SAT || (done ? nLc > 0 : mode != M_FAST)) {
+                    if (!P::SAT || (done ? nLc > 0 : (mode != M_FAST && !wn_round))) {
                         const Sum rsy = P::template gsum<16>(acc.sy), rsyy = P::template gsum<16>(acc.syy);
                         if (lead) { atomicAdd(&sp[2], P::bits(rsy)); atomicAdd(&sp[4], P::bits(rsyy)); }
                     }
                     if (six) {
-                        const uint32_t rn = group_sum<16>(acc.n);
                         const Sum rsx = P::template gsum<16>(acc.sx), rsxx = P::template gsum<16>(acc.sxx);
-                        if (lead) { atomicAdd(&sp[0], (Store)rn); atomicAdd(&sp[1], P::bits(rsx)); atomicAdd(&sp[3], P::bits(rsxx)); }
+                        if (lead) { atomicAdd(&sp[1], P::bits(rsx)); atomicAdd(&sp[3], P::bits(rsxx)); }
+                        if (!wn_round) {
+                            const uint32_t rn = group_sum<16>(acc.n);
+                            if (lead) atomicAdd(&sp[0], (Store)rn);
+                        }
                     }
                 } else {
                     if (P::SAT && mode == M_FAST) {
@@ -1374,7 +1414,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     } else {
                         if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
                         if (on && l == 0) {
-                            sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy);
+                            if (P::SAT && wn_round) { sp[1] = P::bits(acc.sx); sp[3] = P::bits(acc.sxx); sp[5] = P::bits(acc.sxy); }
+                            else { sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy); }
                         }
                     }
                 }
@@ -1388,9 +1429,27 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 Store v[6] = {0, 0, 0, 0, 0, 0};
                 if (one_word) v[5] = sums[tid];
                 else { v[0] = sp[0]; v[1] = sp[1]; v[2] = sp[2]; v[3] = sp[3]; v[4] = sp[4]; v[5] = sp[5]; }
+                // did this cell's round run the WN body?  (the decision was taken per wave and round: no cell of its CPR consecutive
+                // slots touches the T4 row / column; the finishing lanes all sit in wave 0)
+                bool wn_cell = false;
+                if constexpr (P::SAT) {
+                    if (wn_ok) {
+                        const bool t4 = !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2);
+                        const unsigned long long tm = __ballot(t4);
+                        wn_cell = ((tm >> (tid & ~(C::CPR - 1))) & ((1ull << C::CPR) - 1ull)) == 0ull;
+                        if (C::SPARSE && sparse_on) wn_cell = false;       // (those cells took the sparse-correction path, or are T4)
+                    }
+                    if (wn_cell) {
+                        Sum ty = 0, tyy = 0;
+                        const int z = P::SATZ ? cellZ : P::sat_nulls(cellQ);
+                        P::sat_win_sums(ty, tyy, cellQ, z, kb, C::NPX);
+                        v[0] = (Store)(uint32_t)(C::NPX - z); v[2] = P::bits(ty); v[4] = P::bits(tyy);
+                    }
+                }
                 if constexpr (kAPark) {
                     // cells whose n, sx, sxx are the point's constants (minus the corrections that were added above)
                     const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)));
+                    (void)wn_cell;
                     if (!dense) { v[0] += (Store)NV; v[1] += P::bits(SX); v[3] += P::bits(SXX); }
                     if constexpr (P::SAT) {
                         // window-side sums from the table: every cell but the dense ones and the masked CHIPNULL bodies of the
