@@ -57,6 +57,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists
     int32_t lds_off_traj;                           // many-pivot configs: recorded climbs of the pivots beyond the first 64
+    int32_t lds_off_vals, lds_nslot;                // compact configs: value slots of the two-level NCC cache
     // PxU8o: min | max << 16 of the non-null pixels of every 16x16-pixel tile of the two u16 planes (plane coordinates), or null
     const uint32_t *rt0, *rt1;
     int32_t rt_tw;                                  // tiles per plane row

@@ -130,6 +130,7 @@ struct PxU8 {
     static constexpr bool SAT = true;                         // the planes come with a packed summed-area table (sum b | sum b^2 | nulls)
     static constexpr bool SATZ = false;                       // ... whose null counts live in a second table (u16 planes)
     static constexpr bool SAT_CHIP = true;                    // the chip's sums and null count are table look-ups too
+    static constexpr bool WN = false;                         // three-sum body for window-null boxes: measured +1..2 % here (the masks are cheap next to the look-up)
     typedef unsigned long long SatT;
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return (uint32_t)q & ((1u << kSatSqShift8) - 1u); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return (uint32_t)(q >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u); }
@@ -238,6 +239,7 @@ struct PxU16 {
     static constexpr bool SAT = true;                         // sum q | sum q^2 << 25 in one table, null counts in a second one
     static constexpr bool SATZ = true;
     static constexpr bool SAT_CHIP = true;
+    static constexpr bool WN = true;                          // (-2 % on the Laplacian's small chips)
     typedef unsigned long long SatT;
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
@@ -323,6 +325,7 @@ struct PxU8o : PxU8 {
     static constexpr bool SAT = true;
     static constexpr bool SATZ = true;
     static constexpr bool SAT_CHIP = false;
+    static constexpr bool WN = false;                         // (+13 % at ocw 15: the null-count look-up of every dirty box is a second table)
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
@@ -383,7 +386,7 @@ struct PxF32 {
     static constexpr int BPP = 4, G = 1, LOG2G = 0;
     static constexpr bool SRC16 = false;
     static constexpr bool INTEGER = false;
-    static constexpr bool SAT = false, SATZ = false, SAT_CHIP = false;
+    static constexpr bool SAT = false, SATZ = false, SAT_CHIP = false, WN = false;
     typedef unsigned long long SatT;
     __device__ static __forceinline__ unsigned long long sat_s(SatT) { return 0u; }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT) { return 0u; }
@@ -456,6 +459,7 @@ struct PxF32 {
 //      of such a box keeps ONE product stream, sxy = sum fl(a b), instead of three. -------------------------------------------
 struct PxF32i : PxF32 {
     static constexpr bool SAT = true, SATZ = false, SAT_CHIP = true;
+    static constexpr bool WN = true;                          // (-10 % at ocw 16 and 40: three f64 streams instead of six)
     typedef Sat2 SatT;
     __device__ static __forceinline__ double sat_s(const SatT &q) { return (double)(q.a & ((1ull << kSatNullShiftF) - 1ull)); }
     __device__ static __forceinline__ double sat_ss(const SatT &q) { return (double)q.b; }
@@ -479,9 +483,16 @@ struct PxF32i : PxF32 {
     }
 };
 
-template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2, bool CHL_ = false, bool MANY_ = false>
+template <class P_, int OCW_, int LPC_, int NW_ = 1, int MINW_ = 2, bool CHL_ = false, bool MANY_ = false, bool COMPACT_ = false>
 struct PxCfg {
     typedef P_ P;
+    // Compact LDS form, chosen at launch time when the regular carve crosses an occupancy step that this one does not (large
+    // windows: BASELINE C4's 133^2 window needs 50.6 KB per point = 3 points per CU; 40.6 KB = 4):
+    //   * the NCC cache is two-level -- a 16-bit entry per compact cell (bit 15 requested, bit 14 value present, low bits: slot)
+    //     and f32 value slots only for the cells a point really asks for -- instead of one f32 per cell of the whole grid;
+    //     a look-up costs a second, dependent LDS access;
+    //   * the null lists hold 16-bit entries (window coordinates below 256: checked at launch).
+    static constexpr bool COMPACT = COMPACT_;
     static constexpr int MINW = MINW_;                       // occupancy target, waves per SIMD
     static constexpr int OCW = OCW_, LPC = LPC_;
     static constexpr int NW = NW_, NT = 64 * NW_;            // waves / threads per grid point (one workgroup)
@@ -759,9 +770,49 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // scan centres pass the boundary test (:703), i.e. lie in [2, cs-3]; their 3x3 and the fit's 3x3 reach [1, cs-2]: the
     // outermost ring of compact cells is never touched and has no cache word
     const int vpitchc = pt.csx - 2;
-    for (int i = tid; i < vpitchc * (pt.csy - 2); i += NT) val[i] = kUnknown;
-    auto vslot = [&](int cx, int cy) __attribute__((always_inline)) -> float * { return &val[(cy - 1) * vpitchc + (cx - 1)]; };
-    auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float { return val[(cy - 1) * vpitchc + (cx - 1)]; };
+    uint16_t *map16 = reinterpret_cast<uint16_t *>(val);                   // COMPACT: [csy-2][csx-2] entries, value slots behind
+    float *vals = reinterpret_cast<float *>(smem + (C::COMPACT ? p.lds_off_vals : 0));
+    (void)map16; (void)vals;
+    if constexpr (C::COMPACT) { for (int i = tid; i < (vpitchc * (pt.csy - 2) + 1) / 2; i += NT) reinterpret_cast<uint32_t *>(val)[i] = 0u; }
+    else { for (int i = tid; i < vpitchc * (pt.csy - 2); i += NT) val[i] = kUnknown; }
+    auto cell_index = [&](int cx, int cy) __attribute__((always_inline)) -> int { return (cy - 1) * vpitchc + (cx - 1); };
+    auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float {
+        if constexpr (C::COMPACT) {
+            const uint32_t e = map16[cell_index(cx, cy)];
+            const float v = vals[e & 0x3fffu];                             // (slot 0 for an unknown cell: read and dropped)
+            return (e & 0x8000u) ? ((e & 0x4000u) ? v : kWanted) : kUnknown;
+        } else return val[cell_index(cx, cy)];
+    };
+    // claims the cell for evaluation: true for exactly one requester
+    auto claim = [&](int cx, int cy) __attribute__((always_inline)) -> bool {
+        if constexpr (C::COMPACT) {
+            const int i = cell_index(cx, cy);
+            const uint32_t bit = 0x8000u << (16 * (i & 1));
+            return (atomicOr(reinterpret_cast<uint32_t *>(val) + (i >> 1), bit) & bit) == 0u;
+        } else return atomicCAS(reinterpret_cast<uint32_t *>(&val[cell_index(cx, cy)]), __float_as_uint(kUnknown), __float_as_uint(kWanted)) == __float_as_uint(kUnknown);
+    };
+    // COMPACT: the winner of a cell gives it a value slot (qcnt[2] counts them; more than the carve holds -> the general kernel)
+    auto give_slot = [&](int cx, int cy, int slot) __attribute__((always_inline)) { map16[cell_index(cx, cy)] = (uint16_t)(0x8000u | (uint32_t)slot); };
+    auto store_ncc = [&](int cx, int cy, float v) __attribute__((always_inline)) {
+        if constexpr (C::COMPACT) {
+            const int i = cell_index(cx, cy);
+            const uint32_t slot = map16[i] & 0x3fffu;
+            vals[slot] = v;
+            map16[i] = (uint16_t)(0xC000u | slot);
+        } else val[cell_index(cx, cy)] = v;
+    };
+    (void)give_slot;
+    // null lists: 32-bit entries x | y << 16, or (COMPACT) 16-bit entries x | y << 8; absent = all ones
+    auto nl_get = [&](const uint32_t *L, int i) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (C::COMPACT) {
+            const uint32_t e = reinterpret_cast<const uint16_t *>(L)[i];
+            return e == 0xffffu ? 0xffffffffu : ((e & 0xffu) | ((e >> 8) << 16));
+        } else return L[i];
+    };
+    auto nl_put = [&](uint32_t *L, int i, uint32_t x, uint32_t y) __attribute__((always_inline)) {
+        if constexpr (C::COMPACT) reinterpret_cast<uint16_t *>(L)[i] = (uint16_t)(x | (y << 8));
+        else L[i] = x | (y << 16);
+    };
 
     // ---- stage the window as aligned dwords; count nulls and bound them (a5, a6) -----------------
     int ka = 0, kb = 0;                                      // PxU8o: per-point offsets of chip and window (0 otherwise)
@@ -946,7 +997,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                                 for (int q = 0; q < P::G; q++) {
                                     const uint32_t pm = P::lowmask(1) << (8 * P::BPP * q);
-                                    if ((keep & pm) && !(v[k] & pm)) Lw[at++] = (uint32_t)(x0 + q) | ((uint32_t)r << 16);
+                                    if ((keep & pm) && !(v[k] & pm)) nl_put(Lw, at++, (uint32_t)(x0 + q), (uint32_t)r);
                                 }
                             }
                         }
@@ -1075,7 +1126,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                                 for (int k = 0; k < P::G; k++) {
                                     const uint32_t pm = P::lowmask(1) << (8 * P::BPP * k);
-                                    if ((pff & pm) && !(a & pm)) Lc[at++] = (uint32_t)(P::G * j + k) | ((uint32_t)(l + C::LPC * i) << 16);
+                                    if ((pff & pm) && !(a & pm)) nl_put(Lc, at++, (uint32_t)(P::G * j + k), (uint32_t)(l + C::LPC * i));
                                 }
                             }
                         }
@@ -1100,7 +1151,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                                 for (int q = 0; q < P::G; q++) {
                                     const uint32_t pm = P::lowmask(1) << (8 * P::BPP * q);
-                                    if ((pff & pm) && !(AT[k] & pm)) Lc[at++] = (uint32_t)(P::G * j + q) | ((uint32_t)(C::RF * C::LPC + tt / GPR) << 16);
+                                    if ((pff & pm) && !(AT[k] & pm)) nl_put(Lc, at++, (uint32_t)(P::G * j + q), (uint32_t)(C::RF * C::LPC + tt / GPR));
                                 }
                             }
                         }
@@ -1157,10 +1208,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     //      boxes are queued from the front of `list`, dirty boxes from the back; ONE packed counter (clean | dirty << 16)
     //      so that a request costs two dependent LDS round trips.  A batch that outgrows the queue hands the point over
     //      to the general kernel (qcnt[3]).
-    const uint32_t kUnknownBits = __float_as_uint(kUnknown), kWantedBits = __float_as_uint(kWanted);
     auto request = [&](int cx, int cy) __attribute__((always_inline)) {
-        float *slotp = vslot(cx, cy);
-        if (atomicCAS(reinterpret_cast<uint32_t *>(slotp), kUnknownBits, kWantedBits) != kUnknownBits) return;   // asked for or known already
+        if (!claim(cx, cy)) return;                                            // asked for or known already
+        if constexpr (C::COMPACT) {
+            const int slot = atomicAdd(&qcnt[2], 1);
+            if (slot >= p.lds_nslot) { qcnt[3] = 1; return; }
+            give_slot(cx, cy, slot);
+        }
         const bool cl = box_clean(cx, cy);
         const uint32_t q = (uint32_t)atomicAdd(&qcnt[0], cl ? 1 : (1 << 16));
         const int ia = (int)(q & 0xffffu), ib = (int)(q >> 16);
@@ -1193,17 +1247,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // request the whole 3x3 around compact cell (cx0, cy0): the nine compare-and-swaps are issued together, one bump of
     // the packed counter reserves the queue entries of the cells this lane won
     auto request9 = [&](int cx0, int cy0) __attribute__((always_inline)) {
-        uint32_t old[9];
+        bool mine[9];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            float *slotp = vslot(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1));
-            old[j] = atomicCAS(reinterpret_cast<uint32_t *>(slotp), kUnknownBits, kWantedBits);
-        }
+        for (int j = 0; j < 9; j++) mine[j] = claim(cx0 + (j / 3 - 1), cy0 + (j % 3 - 1));
         uint32_t won = 0;
 #pragma unroll
         for (int j = 0; j < 9; j++)
-            if (old[j] == kUnknownBits) won |= 1u << j;
+            if (mine[j]) won |= 1u << j;
         if (!won) return;
+        [[maybe_unused]] int slot0 = 0;
+        if constexpr (C::COMPACT) {
+            slot0 = atomicAdd(&qcnt[2], __popc(won));
+            if (slot0 + __popc(won) > p.lds_nslot) { qcnt[3] = 1; return; }
+        }
         // clean boxes of the 3x3 from three column tests and three row tests (bit j = 3 * column + row, as above): a box is
         // clean if its column range or its row range misses the null bounding box, and it does not touch the T4 row / column
         uint32_t row_ok = 0u, row_t4 = 0u;
@@ -1233,6 +1289,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             const int cx = cx0 + (j / 3 - 1), cy = cy0 + (j % 3 - 1);
             const uint16_t packed = (uint16_t)((cy << 8) | cx);
             if ((wa >> j) & 1u) list[ia++] = packed; else list[lcap - 1 - ib++] = packed;
+            if constexpr (C::COMPACT) give_slot(cx, cy, slot0++);
         }
     };
     // round 0 = the certain set: every pivot whose start passes the boundary test scans its whole 3x3
@@ -1257,17 +1314,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const bool dirty_list = (mode == M_GENERAL);
         // dirty boxes of a null-free chip, planes with a table: the WN body (three sums) instead of the six-sum GENERAL body --
         // except where a cell of the wave's round touches the never-written last row / column (T4: the table does not know it)
-        const bool wn_ok = P::SAT && MIMC3_WN && dirty_list && exc_chip == 0;
+        const bool wn_ok = P::SAT && P::WN && MIMC3_WN && dirty_list && exc_chip == 0;
         // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
         uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
         if constexpr (C::SPARSE) {
             if (sparse_on && cnt > 0) {
                 if (dirty_list) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (l + k * C::LPC < nLw) ew[k] = Lw[l + k * C::LPC];
+                    for (int k = 0; k < 4; k++) if (l + k * C::LPC < nLw) ew[k] = nl_get(Lw, l + k * C::LPC);
                 }
 #pragma unroll
-                for (int k = 0; k < 2; k++) if (l + k * C::LPC < nLc) ec[k] = Lc[l + k * C::LPC];
+                for (int k = 0; k < 2; k++) if (l + k * C::LPC < nLc) ec[k] = nl_get(Lc, l + k * C::LPC);
             }
         }
         // table cells of the one-wave configs park ONE word (sxy): 64 of them fit where 32 six-word slots do, and the f64 finish
@@ -1342,7 +1399,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                             for (int i0 = l + 4 * C::LPC; i0 < nLw; i0 += 4 * C::LPC) {       // long lists: the rest from LDS
                                 uint32_t e[4];
 #pragma unroll
-                                for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLw) ? Lw[i0 + k * C::LPC] : 0xffffffffu;
+                                for (int k = 0; k < 4; k++) e[k] = (i0 + k * C::LPC < nLw) ? nl_get(Lw, i0 + k * C::LPC) : 0xffffffffu;
                                 corr_w(e);
                             }
                         }
@@ -1351,7 +1408,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                             for (int i0 = l + 2 * C::LPC; i0 < nLc; i0 += 2 * C::LPC) {
                                 uint32_t e[2];
 #pragma unroll
-                                for (int k = 0; k < 2; k++) e[k] = (i0 + k * C::LPC < nLc) ? Lc[i0 + k * C::LPC] : 0xffffffffu;
+                                for (int k = 0; k < 2; k++) e[k] = (i0 + k * C::LPC < nLc) ? nl_get(Lc, i0 + k * C::LPC) : 0xffffffffu;
                                 corr_c(e);
                             }
                         }
@@ -1472,7 +1529,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = P::bits(ty); v[3] = P::bits(SXX); v[4] = P::bits(tyy);
                     }
                 }
-                *vslot(cx, cy) = P::ncc(v, sc_chip, sc_win, ka, kb);
+                store_ncc(cx, cy, P::ncc(v, sc_chip, sc_win, ka, kb));
             }
             __syncthreads();
         }
@@ -1928,7 +1985,17 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     if (cap < 16) cap = 16;
     r.lds_list_cap = cap + 16;
     size_t off = (size_t)r.lds_pw * (Dy2 + (full ? 1 : 0));     // + the zero row behind a full-square search area
+    if (C::COMPACT) {    // 16-bit entries for the (csx-2) x (csy-2) cells + value slots for the cells a point asks for
+        const size_t ncell = (size_t)(csx - 2) * (Dy2 - 2 * C::OCW - 1);
+        size_t nslot = 16 * (size_t)max_npiv + 64;
+        if (nslot > ncell) nslot = ncell;
+        if (nslot > 16383) nslot = 16383;
+        r.lds_nslot = (int)nslot;
+        off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += (2 * ncell + 3) & ~(size_t)3;
+        off = (off + 15) & ~(size_t)15; r.lds_off_vals = (int)off; off += 4 * nslot;
+    } else {
     off = (off + 15) & ~(size_t)15; r.lds_off_val = (int)off; off += 4 * (size_t)(csx - 2) * (Dy2 - 2 * C::OCW - 1);   // (csx-2) x (csy-2) cache words
+    }
     off = (off + 15) & ~(size_t)15; r.lds_off_vis = (int)off; off += 4 * (size_t)(((csx + 31) >> 5) * (Dy2 - 2 * C::OCW + 1));
     off = (off + 15) & ~(size_t)15; r.lds_off_list = (int)off; off += 2 * (size_t)r.lds_list_cap;
     off = (off + 15) & ~(size_t)15; r.lds_off_sums = (int)off; off += sizeof(typename C::P::Store) * 6 * kSumBatch + 128;
@@ -1938,8 +2005,8 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     }
     if (C::SPARSE) {
         off = (off + 15) & ~(size_t)15; r.lds_off_chip = (int)off; off += (size_t)C::CPITCH * C::CW;
-        off = (off + 15) & ~(size_t)15; r.lds_off_lw = (int)off; off += 4 * (size_t)kLwCap;
-        off = (off + 15) & ~(size_t)15; r.lds_off_lc = (int)off; off += 4 * (size_t)kLcCap;
+        off = (off + 15) & ~(size_t)15; r.lds_off_lw = (int)off; off += (C::COMPACT ? 2 : 4) * (size_t)kLwCap;
+        off = (off + 15) & ~(size_t)15; r.lds_off_lc = (int)off; off += (C::COMPACT ? 2 : 4) * (size_t)kLcCap;
     }
     off = (off + 15) & ~(size_t)15;
     return off;
@@ -2014,6 +2081,23 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
                 (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N, (double)h[11] / a.N, (double)h[12] / a.N, (double)h[13] / a.N);
     }
     return hipGetLastError();
+}
+
+// Big-chip configurations come in two LDS forms (PxCfg::COMPACT): the compact one is taken when it holds more workgroups per
+// CU than the regular one (at most four: 128 VGPRs x 4 waves per workgroup), or when only it fits at all.
+template <class CD, class CC>
+static hipError_t launch_pick(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
+{
+    MatchU8Args t1 = a, t2 = a;
+    const size_t bd = px_layout<CD>(&t1, max_abs_u, max_abs_v, max_npiv), bc = px_layout<CC>(&t2, max_abs_u, max_abs_v, max_npiv);
+    auto wgs = [](size_t b) { const size_t g = (b + 255) & ~(size_t)255; const int w = g ? (int)(kLdsCapBytes / g) : 0; return w > 4 ? 4 : w; };
+    const bool full = a.win_half > 0;
+    const int Dx2 = full ? 2 * a.win_half + 1 : 2 * (max_abs_u + CD::OCW + 2) + 1, Dy2 = full ? 2 * a.win_half + 1 : 2 * (max_abs_v + CD::OCW + 2) + 1;
+    static const int force = getenv("MIMC3_COMPACT") ? atoi(getenv("MIMC3_COMPACT")) : -1;      // tests / tuning: 0 never, 1 whenever possible
+    const bool possible = Dx2 <= 255 && Dy2 <= 255 && bc <= kLdsCapBytes;                       // 8-bit window coordinates in the null lists
+    const bool want = force >= 0 ? force != 0 : wgs(bc) > wgs(bd);
+    if (possible && want) return launch_cfg<CC>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    return launch_cfg<CD>(a, max_abs_u, max_abs_v, max_npiv, stream);
 }
 
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
@@ -2167,9 +2251,9 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
     case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU8, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     // big chips: 4 waves share one point's LDS image (one cell per wave and round)
-    case 30: return launch_cfg<PxCfg<PxU8, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_cfg<PxCfg<PxU8, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 40: return launch_cfg<PxCfg<PxU8, 40, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30: return launch_pick<PxCfg<PxU8, 30, 64, 4, 4>, PxCfg<PxU8, 30, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_pick<PxCfg<PxU8, 32, 64, 4, 4>, PxCfg<PxU8, 32, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 40: return launch_pick<PxCfg<PxU8, 40, 64, 4, 4>, PxCfg<PxU8, 40, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
 }
