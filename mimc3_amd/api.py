@@ -51,6 +51,7 @@ _lib.mimc3_match_ncc_dlc_dev.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int
 _lib.mimc3_pivot_corridors.argtypes = [_f64p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _vp]
 _lib.mimc3_get_uv_pivot_dev.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_int64), _i32p, _vp]
 _lib.mimc3_match_ncc_dlc_geo.argtypes = [_vp, _f64p, C.c_int32, _i32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _f32p]
+_lib.mimc3_match_ncc_dlc_cor.argtypes = [_vp, _f64p, _vp, C.c_int32, _i32p, C.c_int32, C.c_int32, _f32p]
 _lib.mimc3_qm_launches_per_sweep.restype = C.c_int32
 _lib.mimc3_pivot_extent.argtypes = [_i32p, _i64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32)]
@@ -386,6 +387,16 @@ class Context:
         out = np.empty((xy.shape[0], 3), np.float32)
         _check(_lib.mimc3_match_ncc_dlc_geo(self._h, xy, xy.shape[0], np.ascontiguousarray(offset, np.int32), dt, mpp, aw_sf, aw_cre, ocw,
                                             1 if swap else 0, out), "matching_ncc_dlc_geo")
+        return out
+
+    def matching_ncc_dlc_cor(self, xyuvav, cor, offset, ocw, swap=False, out=None):
+        """the same with the corridors given (pivot_corridors(): once per grid, whatever the chip size); `out` may be a pinned array"""
+        xy = np.ascontiguousarray(xyuvav, np.float64)
+        if out is None:
+            out = np.empty((xy.shape[0], 3), np.float32)
+        cor = np.ascontiguousarray(cor, np.uint8)
+        _check(_lib.mimc3_match_ncc_dlc_cor(self._h, xy, cor.ctypes.data, xy.shape[0], np.ascontiguousarray(offset, np.int32), ocw, 1 if swap else 0, out),
+               "matching_ncc_dlc_cor")
         return out
 
     def get_uv_pivot_dev(self, d_xyuvav, d_cor, n, ocw, d_piv_off, d_piv_uv=None, d_piv_uv_neg=None, cap=0, stream=0):

@@ -82,6 +82,8 @@ struct mimc3_ctx {
     int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
     DevBuf pcor, pcnt, pext;            // device pivots: corridors [N] x 24 B, counts [N], extents + total (24 B)
+    int32_t xy_stride = 6, xy_col = 2;  // where the matcher finds a point's (u, v) in its `xyuvav` argument: xyuvav rows, or (internal) a packed [N][2] array
+    hipEvent_t ev_chunk[2][8] = {};     // mimc3_match_ncc_dlc_cor: "chunk uploaded + counted" / "chunk matched"
     DevBuf qm_io, qm_work;              // QM staging / workspace
     DevBuf n1_io, n1_work;              // clustering / dpf0 / dpf1 staging and workspace
     const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
@@ -260,6 +262,7 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
     for (auto &st : c->aux) if (st) (void)hipStreamDestroy(st);
     for (auto &ev : c->ev_side) if (ev) (void)hipEventDestroy(ev);
+    for (auto &row : c->ev_chunk) for (auto &ev : row) if (ev) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -530,7 +533,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     HIP_TRY(hipSetDevice(c->device));
     mimc3::MatchArgs a{};
     a.i0 = c->d_i0; a.i1 = c->d_i1; a.H = c->H; a.W = c->W;
-    a.xyuvav = d_xyuvav; a.N = N; a.off_u = off_u; a.off_v = off_v;
+    a.xyuvav = d_xyuvav; a.xy_stride = c->xy_stride; a.xy_col = c->xy_col; a.N = N; a.off_u = off_u; a.off_v = off_v;
     a.piv_uv = d_piv_uv; a.piv_off = d_piv_off; a.ocw = ocw; a.swap = swap ? 1 : 0;
     a.thr = min_dn_threshold();
     a.out = d_out;
@@ -578,7 +581,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
     if (want_u8 || want_u16 || want_f32x) {
         mimc3::MatchU8Args u{};
         u.Wp = c->Wp; u.pad = mimc3::kU8Pad; u.H = c->H; u.W = c->W; u.thr = a.thr;
-        u.xyuvav = d_xyuvav; u.N = N; u.off_u = off_u; u.off_v = off_v;
+        u.xyuvav = d_xyuvav; u.xy_stride = c->xy_stride; u.xy_col = c->xy_col; u.N = N; u.off_u = off_u; u.off_v = off_v;
         u.piv_uv = d_piv_uv; u.piv_off = d_piv_off; u.ocw = ocw; u.swap = swap ? 1 : 0; u.out = d_out;
         u.win_half = c->win_half;
         // points whose per-point NCC cache overflows (very long climbs) are appended to a device list and
@@ -689,7 +692,7 @@ static int pivots_count(mimc3_ctx *c, const double *d_xy, const void *d_cor, int
 {
     HIP_TRY(c->pcnt.reserve(sizeof(int32_t) * (size_t)N));
     HIP_TRY(c->pext.reserve(64));
-    HIP_TRY(mimc3::launch_pivot_count(d_xy, static_cast<const mimc3::CorridorDev *>(d_cor), N, ocw, c->H, c->W, static_cast<int32_t *>(c->pcnt.p), d_off,
+    HIP_TRY(mimc3::launch_pivot_count(d_xy, 6, 2, static_cast<const mimc3::CorridorDev *>(d_cor), N, ocw, c->H, c->W, static_cast<int32_t *>(c->pcnt.p), d_off,
                                       static_cast<int32_t *>(c->pext.p), s));
     int32_t h[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h, c->pext.p, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -717,38 +720,112 @@ extern "C" int mimc3_get_uv_pivot_dev(mimc3_ctx *c, const double *d_xyuvav, cons
     return 0;
 }
 
-// get_uv_pivot + matching_ncc_dlc_2 (MIMC_main.c:264-267 / :281-284) in one call; only 24 bytes of corridor per point are uploaded
+// get_uv_pivot + matching_ncc_dlc_2 (MIMC_main.c:264-267 / :281-284) in one call, corridors given (host).  What crosses PCIe per
+// grid point: its (u, v) (16 B: the matcher and the pivot kernel read nothing else of an xyuvav row), its corridor (24 B), its
+// result (12 B).  The grid goes through in chunks: uploads + pivot counts on one copy stream, lists + matcher on the context's
+// stream, downloads on a second copy stream -- the transfers of chunk k+1 / k-1 run under the matcher of chunk k.
+extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const void *cor, int32_t N, const int32_t offset[2], int32_t ocw,
+                                       int32_t swap, float *out)
+{
+    if (!c || !xyuvav || !cor || !offset || !out || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_cor: bad argument");
+    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_cor: images not set");
+    if (!c->aux[0] || !c->aux[1]) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_cor: the context has no copy streams");
+    HIP_TRY(hipSetDevice(c->device));
+    const mimc3::CorridorPOD *hc = static_cast<const mimc3::CorridorPOD *>(cor);
+    // pack (u, v), check the chips against the image (see mimc3_match_ncc_dlc), bound the list sizes: n(g) <= length / |step| + 2
+    void *huv_v = nullptr;
+    RC_TRY(mimc3_ctx_host_workspace(c, 6, 16 * (size_t)N, &huv_v));                      // pinned, kept across calls
+    double *huv = static_cast<double *>(huv_v);
+    const int K = N >= 40000 ? 4 : 1;
+    int32_t lo[9];
+    for (int k = 0; k <= K; k++) lo[k] = (int32_t)((int64_t)N * k / K);
+    int64_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; k++)
+        for (int32_t g = lo[k]; g < lo[k + 1]; ++g) {
+            const double gu = xyuvav[6 * (size_t)g + 2], gv = xyuvav[6 * (size_t)g + 3];
+            const int32_t u0 = (int32_t)gu, v0 = (int32_t)gv;
+            if (u0 - ocw < 0 || u0 + ocw >= c->W || v0 - ocw < 0 || v0 + ocw >= c->H)
+                return mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc_cor: grid point " + std::to_string(g) + " chip leaves the image");
+            huv[2 * (size_t)g] = gu; huv[2 * (size_t)g + 1] = gv;
+            const double q = hc[g].length / (double)hc[g].norm_incr;
+            cap[k] += (q > 0.0 && q < 1e6 ? (int64_t)q : 0) + 2;
+        }
+    int64_t cap_all = 0;
+    for (int k = 0; k < K; k++) cap_all += cap[k];
+    HIP_TRY(c->xy.reserve(16 * (size_t)N));
+    HIP_TRY(c->pcor.reserve(sizeof(mimc3::CorridorPOD) * (size_t)N));
+    HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + K)));
+    HIP_TRY(c->puv.reserve(sizeof(int32_t) * 2 * (size_t)cap_all));
+    HIP_TRY(c->pcnt.reserve(sizeof(int32_t) * (size_t)N));
+    HIP_TRY(c->pext.reserve(64 * (size_t)K));
+    HIP_TRY(c->out.reserve(sizeof(float) * 3 * (size_t)N));
+    void *hext_v = nullptr;
+    RC_TRY(mimc3_ctx_host_workspace(c, 5, 64 * (size_t)K, &hext_v));
+    int32_t *hext = static_cast<int32_t *>(hext_v);
+    for (int j = 0; j < 2; j++)
+        for (int k = 0; k < K; k++)
+            if (!c->ev_chunk[j][k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[j][k], hipEventDisableTiming));
+    hipStream_t up = c->aux[0], down = c->aux[1], s = c->stream;
+    double *d_uv = static_cast<double *>(c->xy.p);
+    char *d_cor = static_cast<char *>(c->pcor.p);
+    // ---- copy stream: per chunk (u, v) + corridors up, pivot counts + offsets, the 24 bytes that size lists and launch back to the host
+    for (int k = 0; k < K; k++) {
+        const size_t g0 = (size_t)lo[k], n = (size_t)(lo[k + 1] - lo[k]);
+        HIP_TRY(hipMemcpyAsync(d_uv + 2 * g0, huv + 2 * g0, 16 * n, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d_cor + sizeof(mimc3::CorridorPOD) * g0, hc + g0, sizeof(mimc3::CorridorPOD) * n, hipMemcpyHostToDevice, up));
+        HIP_TRY(mimc3::launch_pivot_count(d_uv + 2 * g0, 2, 0, reinterpret_cast<const mimc3::CorridorDev *>(d_cor) + g0, (int)n, ocw, c->H, c->W,
+                                          static_cast<int32_t *>(c->pcnt.p) + g0, static_cast<int64_t *>(c->poff.p) + g0 + k,
+                                          reinterpret_cast<int32_t *>(static_cast<char *>(c->pext.p) + 64 * (size_t)k), up));
+        HIP_TRY(hipMemcpyAsync(hext + 16 * k, static_cast<char *>(c->pext.p) + 64 * (size_t)k, 24, hipMemcpyDeviceToHost, up));
+        HIP_TRY(hipEventRecord(c->ev_chunk[0][k], up));
+    }
+    // ---- the context's stream: lists + matcher per chunk; second copy stream: results down
+    int rc = 0;
+    int64_t uv_base = 0;
+    const int32_t keep_stride = c->xy_stride, keep_col = c->xy_col;
+    c->xy_stride = 2; c->xy_col = 0;
+    for (int k = 0; k < K && !rc; k++) {
+        const size_t g0 = (size_t)lo[k];
+        const int32_t n = lo[k + 1] - lo[k];
+        hipError_t e = hipEventSynchronize(c->ev_chunk[0][k]);
+        if (e != hipSuccess) { rc = mimc3::hip_fail(e, "chunk upload"); break; }
+        const int32_t *h = hext + 16 * k;
+        int64_t total = 0;
+        std::memcpy(&total, &h[4], sizeof(total));
+        if (h[3]) { rc = mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc_cor: a grid point has zero pivots (too close to the image edge)"); break; }
+        if (total > cap[k]) { rc = mimc3::fail(MIMC3_ECAP, "mimc3_match_ncc_dlc_cor: internal pivot bound exceeded"); break; }
+        int32_t *uv = static_cast<int32_t *>(c->puv.p) + 2 * uv_base;
+        const int64_t *off = static_cast<const int64_t *>(c->poff.p) + g0 + k;
+        e = hipStreamWaitEvent(s, c->ev_chunk[0][k], 0);
+        if (e == hipSuccess) e = mimc3::launch_pivot_fill(reinterpret_cast<const mimc3::CorridorDev *>(d_cor) + g0, off, n, swap ? nullptr : uv, swap ? uv : nullptr, s);
+        if (e != hipSuccess) { rc = mimc3::hip_fail(e, "pivot lists"); break; }
+        float *d_out = static_cast<float *>(c->out.p) + 3 * g0;
+        rc = mimc3_match_ncc_dlc_dev(c, d_uv + 2 * g0, n, offset[0], offset[1], uv, off, h[0], h[1], h[2], ocw, swap, d_out, s);
+        if (rc) break;
+        e = hipEventRecord(c->ev_chunk[1][k], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(down, c->ev_chunk[1][k], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(out + 3 * g0, d_out, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, down);
+        if (e != hipSuccess) { rc = mimc3::hip_fail(e, "result download"); break; }
+        uv_base += cap[k];
+    }
+    c->xy_stride = keep_stride; c->xy_col = keep_col;
+    // every stream drains before the buffers are reused (also on the error paths)
+    hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(s), e3 = hipStreamSynchronize(down);
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return mimc3::hip_fail(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "mimc3_match_ncc_dlc_cor");
+    return 0;
+}
+
+// the same with the corridors made here (the libm half of get_uv_pivot: threaded host code)
 extern "C" int mimc3_match_ncc_dlc_geo(mimc3_ctx *c, const double *xyuvav, int32_t N, const int32_t offset[2], float dt, float mpp, float aw_sf,
                                        float aw_cre, int32_t ocw, int32_t swap, float *out)
 {
     if (!c || !xyuvav || !offset || !out || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_geo: bad argument");
-    if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_geo: images not set");
-    for (int32_t g = 0; g < N; ++g) {                       // (see mimc3_match_ncc_dlc: the reference reads out of bounds here)
-        const int32_t u0 = (int32_t)xyuvav[6 * (size_t)g + 2], v0 = (int32_t)xyuvav[6 * (size_t)g + 3];
-        if (u0 - ocw < 0 || u0 + ocw >= c->W || v0 - ocw < 0 || v0 + ocw >= c->H)
-            return mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc_geo: grid point " + std::to_string(g) + " chip leaves the image");
-    }
     HIP_TRY(hipSetDevice(c->device));
     void *hcor = nullptr;
     RC_TRY(mimc3_ctx_host_workspace(c, 7, sizeof(mimc3::CorridorPOD) * (size_t)N, &hcor));      // pinned, kept across calls
     mimc3::pivot_corridors(xyuvav, N, dt, mpp, aw_sf, aw_cre, static_cast<mimc3::CorridorPOD *>(hcor));
-    HIP_TRY(c->xy.reserve(sizeof(double) * 6 * (size_t)N));
-    HIP_TRY(c->pcor.reserve(sizeof(mimc3::CorridorPOD) * (size_t)N));
-    HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + 1)));
-    HIP_TRY(c->out.reserve(sizeof(float) * 3 * (size_t)N));
-    RC_TRY(h2d_copy(c, c->xy.p, xyuvav, sizeof(double) * 6 * (size_t)N));
-    RC_TRY(h2d_copy(c, c->pcor.p, hcor, sizeof(mimc3::CorridorPOD) * (size_t)N));
-    int64_t total = 0;
-    int32_t ext[3] = {0, 0, 0};
-    RC_TRY(pivots_count(c, static_cast<const double *>(c->xy.p), c->pcor.p, N, ocw, static_cast<int64_t *>(c->poff.p), c->stream, &total, ext));
-    HIP_TRY(c->puv.reserve(sizeof(int32_t) * 2 * (size_t)total));
-    int32_t *uv = static_cast<int32_t *>(c->puv.p);
-    HIP_TRY(mimc3::launch_pivot_fill(static_cast<const mimc3::CorridorDev *>(c->pcor.p), static_cast<const int64_t *>(c->poff.p), N, swap ? nullptr : uv,
-                                     swap ? uv : nullptr, c->stream));
-    int rc = mimc3_match_ncc_dlc_dev(c, static_cast<const double *>(c->xy.p), N, offset[0], offset[1], uv, static_cast<const int64_t *>(c->poff.p), ext[0],
-                                     ext[1], ext[2], ocw, swap, static_cast<float *>(c->out.p), c->stream);
-    if (rc) return rc;
-    return d2h_copy(c, out, c->out.p, sizeof(float) * 3 * (size_t)N);
+    return mimc3_match_ncc_dlc_cor(c, xyuvav, hcor, N, offset, ocw, swap, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ struct MatchArgs {
     const float *i0, *i1;        // device images [H][W]
     int32_t H, W;
     const double *xyuvav;        // device [N][6]
+    int32_t xy_stride, xy_col;   // the points' (u, v) sit at xyuvav[xy_stride * g + xy_col + {0, 1}]: 6, 2 (xyuvav rows) or 2, 0 (packed [N][2])
     int32_t N;
     int32_t off_u, off_v;        // CP offset, added to the search centre only (MIMC_module.c:827-828)
     const int32_t *piv_uv;       // device CSR payload [P][2]
@@ -43,6 +44,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     double scale0, scale1;          // u16 policy: plane k stores value * 2^s_k; scale_k = 2^-s_k (1.0 otherwise)
     int32_t H, W;
     const double *xyuvav;
+    int32_t xy_stride, xy_col;      // see MatchArgs
     int32_t N;
     int32_t off_u, off_v;
     const int32_t *piv_uv;

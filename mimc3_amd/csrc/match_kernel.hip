@@ -113,8 +113,8 @@ __device__ __forceinline__ void match_point_f32(const MatchArgs &p, int gidx, un
     const float *win_img = p.swap ? p.i0 : p.i1;
 
     // ---- point header ---------------------------------------------------------------------
-    const double *row = p.xyuvav + 6 * (size_t)gidx;
-    const int u0 = (int)row[2], v0 = (int)row[3];          // T6 truncation (:822-823)
+    const double *row = p.xyuvav + (size_t)p.xy_stride * (size_t)gidx + p.xy_col;
+    const int u0 = (int)row[0], v0 = (int)row[1];          // T6 truncation (:822-823)
     const int64_t pbeg = p.piv_off[gidx];
     const int npiv = (int)(p.piv_off[gidx + 1] - pbeg);
     const int32_t *pv_g = p.piv_uv + 2 * pbeg;

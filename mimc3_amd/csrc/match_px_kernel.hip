@@ -39,6 +39,9 @@
 #ifndef MIMC3_WN
 #define MIMC3_WN 1              // window-null cells of a clean chip: three sums + table instead of six
 #endif
+#ifndef MIMC3_NULL_FLAGS
+#define MIMC3_NULL_FLAGS 1      // sparse-correction configs: skip the window-null walk of dirty-list boxes that hold no null (table look-up)
+#endif
 #ifndef MIMC3_OPQ_SMALL
 #define MIMC3_OPQ_SMALL 0       // keep the chip-derived masks of the small chips out of registers too
 #endif
@@ -690,8 +693,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     const int Wp = p.Wp, PAD = p.pad;
 
     // ---- point header -------------------------------------------------------------------------
-    const double *row = p.xyuvav + 6 * (size_t)gidx;
-    const int u0 = (int)row[2], v0 = (int)row[3];
+    const double *row = p.xyuvav + (size_t)p.xy_stride * (size_t)gidx + p.xy_col;   // (u, v): columns 2, 3 of an xyuvav row, or a packed [N][2] array
+    const int u0 = (int)row[0], v0 = (int)row[1];
     const int64_t pbeg = p.piv_off[gidx];
     const int npiv = (int)(p.piv_off[gidx + 1] - pbeg);
     const int32_t *pv_g = p.piv_uv + 2 * pbeg;
@@ -1351,6 +1354,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                 }
             }
+            // Sparse-correction configs: a box is on the dirty list because it meets the BOUNDING BOX of the window's nulls; the
+            // table knows whether it holds a null at all.  Boxes without one skip the walk over the window-null list (their
+            // corrections to n, sx, sxx are zero): the finishing lanes publish one flag per cell of the batch.
+            [[maybe_unused]] unsigned char *nzf = reinterpret_cast<unsigned char *>(&qcnt[24]);       // [kSumBatch]
+            constexpr bool kNullFlags = C::SPARSE && P::SAT && !MIMC3_SAT_DEFER && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
+            if constexpr (kNullFlags) {
+                if (dirty_list && sparse_on) {
+                    if (tid < nb) nzf[tid] = (unsigned char)((P::SATZ ? cellZ : P::sat_nulls(cellQ)) != 0);
+                    __syncthreads();
+                }
+            }
             for (int r0 = 0; r0 < nb; r0 += C::CPR * NW) {
                 const int slot = r0 + wave * C::CPR + grp;
                 const bool on = slot < nb;
@@ -1394,7 +1408,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                             for (int k = 0; k < 2; k++) { csy += bv[k]; csyy += (Sum)__umul24(bv[k], bv[k]); }
                         };
-                        if (dirty_list) {
+                        bool wnull = dirty_list;
+                        if constexpr (kNullFlags) wnull = dirty_list && on && nzf[slot] != 0;
+                        six = wnull;
+                        if (wnull) {
                             corr_w(ew);
                             for (int i0 = l + 4 * C::LPC; i0 < nLw; i0 += 4 * C::LPC) {       // long lists: the rest from LDS
                                 uint32_t e[4];
@@ -2045,7 +2062,8 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     //  offsets and u16 policies see in the program, lose: d/dx +1.3 / +2 %, Laplacian +4.4 %)
     //  (the small chips of those two policies as well: Laplacian ocw 7 / 15 -3.2 / -5 %, d/dx ocw 15 -1.3 % without look-ahead)
     constexpr bool kNoisy = C::P::SRC16 || std::is_same<typename C::P, PxU16>::value;
-    a.lookahead = look >= 0 ? look : (kNoisy ? 0 : 1);
+    // (long corridors on a big chip -- BASELINE C4: 33 pivots, ocw 32 -- lose with it too: 166.7 vs 165.6 ms)
+    a.lookahead = look >= 0 ? look : ((kNoisy || (C::LPC >= 64 && max_npiv > 24)) ? 0 : 1);
     a.debug_stop = dbg;
     static unsigned long long *d_stats = nullptr;
     static const bool want_stats = getenv("MIMC3_U8_STATS") != nullptr;

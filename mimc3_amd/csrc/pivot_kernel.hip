@@ -19,14 +19,15 @@
 
 namespace mimc3 {
 
-__global__ __launch_bounds__(256) void pivot_count(const double *__restrict__ xyuvav, const CorridorDev *__restrict__ cor, int N, int ocw,
-                                                   int H, int W, int32_t *__restrict__ cnt, int32_t *__restrict__ ext)
+__global__ __launch_bounds__(256) void pivot_count(const double *__restrict__ xyuvav, int xy_stride, int xy_col, const CorridorDev *__restrict__ cor, int N,
+                                                   int ocw, int H, int W, int32_t *__restrict__ cnt, int32_t *__restrict__ ext)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     int n = 0, au = 0, av = 0;
     if (g < N) {
         const CorridorDev c = cor[g];
-        const float fu = (float)xyuvav[6 * (size_t)g + 2], fv = (float)xyuvav[6 * (size_t)g + 3], fo = (float)ocw;
+        const double *row = xyuvav + (size_t)xy_stride * (size_t)g + xy_col;
+        const float fu = (float)row[0], fv = (float)row[1], fo = (float)ocw;
         const float wmax = (float)(W - 1), hmax = (float)(H - 1);
         float u = 0.0f, v = 0.0f, pu = 0.0f, pv = 0.0f;              // (pu, pv): the sums that make the LAST pivot
         for (;;) {
@@ -99,12 +100,12 @@ __global__ __launch_bounds__(256) void pivot_fill(const CorridorDev *__restrict_
     }
 }
 
-hipError_t launch_pivot_count(const double *d_xyuvav, const CorridorDev *d_cor, int N, int ocw, int H, int W, int32_t *d_cnt, int64_t *d_piv_off,
-                              int32_t *d_ext6, hipStream_t s)
+hipError_t launch_pivot_count(const double *d_xyuvav, int xy_stride, int xy_col, const CorridorDev *d_cor, int N, int ocw, int H, int W, int32_t *d_cnt,
+                              int64_t *d_piv_off, int32_t *d_ext6, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(d_ext6, 0, 6 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pivot_count, dim3((N + 255) / 256), dim3(256), 0, s, d_xyuvav, d_cor, N, ocw, H, W, d_cnt, d_ext6);
+    hipLaunchKernelGGL(pivot_count, dim3((N + 255) / 256), dim3(256), 0, s, d_xyuvav, xy_stride, xy_col, d_cor, N, ocw, H, W, d_cnt, d_ext6);
     hipLaunchKernelGGL(pivot_scan, dim3(1), dim3(1024), 0, s, d_cnt, N, d_piv_off, reinterpret_cast<int64_t *>(d_ext6 + 4));
     return hipGetLastError();
 }

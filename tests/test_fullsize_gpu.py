@@ -76,6 +76,19 @@ def test_c2_all_200k_points_vs_reference(api, c2, mode):
     assert ok.mean() > 0.9 and abs(np.median(got[ok, 0]) - 4) < 0.1 and abs(np.median(got[ok, 1]) + 4) < 0.1
 
 
+def test_c2_fused_pivot_entry_chunked(api, c2):
+    """mimc3_match_ncc_dlc_geo / _cor at C2 size: corridors from the host, pivot lists made on the device, the grid pipelined through
+    in four chunks (uploads and downloads under the matcher) -- the same bits as the reference on all 200,000 points"""
+    c, off, uv, want = c2
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_geo(c.xyuvav, c.offset, c.dt, c.mpp, c.ocw)
+        cor = api.pivot_corridors(c.xyuvav, c.dt, c.mpp)
+        got2 = ctx.matching_ncc_dlc_cor(c.xyuvav, cor, c.offset, c.ocw, out=api.pinned_empty((c.n, 3), np.float32))
+    assert_bits_equal(got, want, "C2 fused entry")
+    assert_bits_equal(np.array(got2), want, "C2 fused entry, corridors given, pinned result")
+
+
 def test_c2_swapped_pass_vs_reference(api, checker, c2):
     """the CLI's second call per chip size: images exchanged, offset and pivots negated (MIMC_main.c:272-293)"""
     c, off, uv, _ = c2
