@@ -74,8 +74,9 @@ struct mimc3_ctx {
     int shift0 = 0, shift1 = 0;
     DevBuf fpl0, fpl1;                  // zero-bordered f32 planes (register-tiled f32 kernel), built on first use
     bool fplanes_ok = false;
-    DevBuf fsat0, fsat1;                // their 16-byte summed-area tables when every pixel is an integer in [0, 2^18) (16-bit DN)
+    DevBuf fsat0, fsat1;                // their 16-byte summed-area tables when every pixel (x 1 or x 8) is an integer in [0, 2^20) (16-bit DN and its filtered forms)
     bool f32i_ok = false;
+    int fshift0 = 0, fshift1 = 0;      // pixel x 2^shift is the integer the table sums
     int32_t Wp = 0;
     bool u8_ok = false;                 // both images proven to be integers in [0,255]
     int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
@@ -497,24 +498,27 @@ static int build_f32_planes(mimc3_ctx *c, hipStream_t s)
     HIP_TRY(mimc3::launch_prep_f32(c->d_i0, c->H, c->W, static_cast<float *>(c->fpl0.p), c->Wp, mimc3::kU8Pad, s));
     HIP_TRY(mimc3::launch_prep_f32(c->d_i1, c->H, c->W, static_cast<float *>(c->fpl1.p), c->Wp, mimc3::kU8Pad, s));
     c->fplanes_ok = true;
-    // 16-bit DN (every pixel an integer in [0, 2^18)): the f64 sums of the reference are exact integers in any order, and the
+    // 16-bit DN and its filtered forms (every pixel, x 1 or x 8, an integer in [0, 2^20)): the f64 sums of the reference are exact integers in any order, and the
     // planes get summed-area tables like the integer planes (one read-back per image pair)
     c->f32i_ok = false;
     if (!getenv("MIMC3_NO_F32_TABLES")) {
-        int not_int = 1;
-        HIP_TRY(c->flag.reserve(sizeof(int)));
-        HIP_TRY(hipMemsetAsync(c->flag.p, 0, sizeof(int), s));
+        int fl[2] = {3, 3};
+        HIP_TRY(c->flag.reserve(2 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(c->flag.p, 0, 2 * sizeof(int), s));
         HIP_TRY(mimc3::launch_detect_int16(c->d_i0, (size_t)c->H * c->W, static_cast<int *>(c->flag.p), s));
-        HIP_TRY(mimc3::launch_detect_int16(c->d_i1, (size_t)c->H * c->W, static_cast<int *>(c->flag.p), s));
-        HIP_TRY(hipMemcpyAsync(&not_int, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(mimc3::launch_detect_int16(c->d_i1, (size_t)c->H * c->W, static_cast<int *>(c->flag.p) + 1, s));
+        HIP_TRY(hipMemcpyAsync(fl, c->flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (!not_int) {
+        auto pick = [](int f) { return (f & 1) == 0 ? 0 : ((f & 2) == 0 ? 3 : -1); };      // integers, or multiples of 1/8 (the Laplacian, MIMC_main.c:188-196)
+        const int s0 = pick(fl[0]), s1 = pick(fl[1]);
+        if (s0 >= 0 && s1 >= 0) {
+            c->fshift0 = s0; c->fshift1 = s1;
             const int Hp = c->H + 2 * mimc3::kU8Pad;
             HIP_TRY(c->fsat0.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
             HIP_TRY(c->fsat1.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
             HIP_TRY(c->sat_tmp.reserve(mimc3::sat2_scratch_bytes(Hp, c->Wp)));
-            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl0.p), Hp, c->Wp, static_cast<mimc3::Sat2 *>(c->fsat0.p), c->sat_tmp.p, s));
-            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl1.p), Hp, c->Wp, static_cast<mimc3::Sat2 *>(c->fsat1.p), c->sat_tmp.p, s));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl0.p), Hp, c->Wp, s0, static_cast<mimc3::Sat2 *>(c->fsat0.p), c->sat_tmp.p, s));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl1.p), Hp, c->Wp, s1, static_cast<mimc3::Sat2 *>(c->fsat1.p), c->sat_tmp.p, s));
             c->f32i_ok = true;
         }
     }
@@ -623,7 +627,10 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         } else {
             RC_TRY(build_f32_planes(c, s));
             u.p0 = static_cast<const unsigned char *>(c->fpl0.p); u.p1 = static_cast<const unsigned char *>(c->fpl1.p);
-            if (c->f32i_ok) { u.sat0 = c->fsat0.p; u.sat1 = c->fsat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp); }
+            if (c->f32i_ok) {
+                u.sat0 = c->fsat0.p; u.sat1 = c->fsat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
+                u.scale0 = 1.0 / (double)(1 << c->fshift0); u.scale1 = 1.0 / (double)(1 << c->fshift1);
+            }
             e = mimc3::launch_match_f32x(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 2;
         }
@@ -732,6 +739,14 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
     if (!c->aux[0] || !c->aux[1]) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_cor: the context has no copy streams");
     HIP_TRY(hipSetDevice(c->device));
     const mimc3::CorridorPOD *hc = static_cast<const mimc3::CorridorPOD *>(cor);
+    static const bool io_tm = getenv("MIMC3_IO_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!io_tm) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mimc3 io] %-18s %7.3f ms\n", w, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // pack (u, v), check the chips against the image (see mimc3_match_ncc_dlc), bound the list sizes: n(g) <= length / |step| + 2
     void *huv_v = nullptr;
     RC_TRY(mimc3_ctx_host_workspace(c, 6, 16 * (size_t)N, &huv_v));                      // pinned, kept across calls
@@ -752,6 +767,7 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
         }
     int64_t cap_all = 0;
     for (int k = 0; k < K; k++) cap_all += cap[k];
+    lap("pack + bounds");
     HIP_TRY(c->xy.reserve(16 * (size_t)N));
     HIP_TRY(c->pcor.reserve(sizeof(mimc3::CorridorPOD) * (size_t)N));
     HIP_TRY(c->poff.reserve(sizeof(int64_t) * ((size_t)N + K)));
@@ -779,6 +795,7 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
         HIP_TRY(hipMemcpyAsync(hext + 16 * k, static_cast<char *>(c->pext.p) + 64 * (size_t)k, 24, hipMemcpyDeviceToHost, up));
         HIP_TRY(hipEventRecord(c->ev_chunk[0][k], up));
     }
+    lap("uploads enqueued");
     // ---- the context's stream: lists + matcher per chunk; second copy stream: results down
     int rc = 0;
     int64_t uv_base = 0;
@@ -809,8 +826,10 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
         uv_base += cap[k];
     }
     c->xy_stride = keep_stride; c->xy_col = keep_col;
+    lap("chunks enqueued");
     // every stream drains before the buffers are reused (also on the error paths)
     hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(s), e3 = hipStreamSynchronize(down);
+    lap("drained");
     if (rc) return rc;
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return mimc3::hip_fail(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "mimc3_match_ncc_dlc_cor");
     return 0;

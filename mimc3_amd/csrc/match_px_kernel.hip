@@ -140,7 +140,7 @@ struct PxU8 {
     __device__ static __forceinline__ int sat_nulls(SatT q) { return (int)(q >> kSatNullShift8); }
     // window-side sums of a box from its table entry, in the units the kernel accumulates in (z = nulls in the box, k = the
     // window offset of the per-point-offset policy, npx = pixels of the box)
-    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int, int, int) { sy = (uint32_t)sat_s(q); syy = (uint32_t)sat_ss(q); }
+    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int, int, int, double) { sy = (uint32_t)sat_s(q); syy = (uint32_t)sat_ss(q); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *p; }
     typedef uint32_t Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 4 ? 0xffffffffu : ((1u << (8 * npx)) - 1u); }
@@ -247,7 +247,7 @@ struct PxU16 {
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
-    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
+    __device__ static __forceinline__ void sat_win_sums(unsigned long long &sy, unsigned long long &syy, SatT q, int, int, int, double) { sy = sat_s(q); syy = sat_ss(q); }
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const unsigned short *>(p); }
     typedef unsigned long long Sum;                    // per-lane partials stay < 2^32; the reduction needs 64 bits
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 2 ? 0xffffffffu : (npx == 1 ? 0x0000ffffu : 0u); }
@@ -332,7 +332,7 @@ struct PxU8o : PxU8 {
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return q & ((1ull << kSatSqShift16) - 1ull); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return q >> kSatSqShift16; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
-    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int z, int k, int npx)
+    __device__ static __forceinline__ void sat_win_sums(uint32_t &sy, uint32_t &syy, SatT q, int z, int k, int npx, double)
     {
         const long long m = npx - z, K = k, s1 = (long long)sat_s(q), s2 = (long long)sat_ss(q);
         sy = (uint32_t)(s1 - K * m);                                // sums of bytes / squared bytes over <= 81^2 pixels: < 2^32
@@ -394,7 +394,7 @@ struct PxF32 {
     __device__ static __forceinline__ unsigned long long sat_s(SatT) { return 0u; }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT) { return 0u; }
     __device__ static __forceinline__ int sat_nulls(SatT) { return 0; }
-    __device__ static __forceinline__ void sat_win_sums(double &, double &, SatT, int, int, int) {}
+    __device__ static __forceinline__ void sat_win_sums(double &, double &, SatT, int, int, int, double) {}
     __device__ static __forceinline__ uint32_t px_at(const unsigned char *p) { return *reinterpret_cast<const uint32_t *>(p); }
     typedef double Sum;
     static constexpr uint32_t lowmask_c(int npx) { return npx >= 1 ? 0xffffffffu : 0u; }
@@ -455,8 +455,8 @@ struct PxF32 {
     }
 };
 
-// ---- pixel policy: f32 planes whose pixels are all INTEGERS in [0, 2^18) (16-bit DN and the integer gradients of such images).  The reference's arithmetic is the
-//      f32 policy's -- f32 products that round above 2^24 (T1), f64 sums -- but every term is an integer below 2^36 and every
+// ---- pixel policy: f32 planes whose pixels are all INTEGERS in [0, 2^20), possibly in units of 1/8 (16-bit DN, the integer gradients and the Laplacian of such images).  The reference's arithmetic is the
+//      f32 policy's -- f32 products that round above 2^24 (T1), f64 sums -- but every term is an integer below 2^40 and every
 //      sum an integer below 2^53: exact in any order, so the window-side sums of a null-free box (sum b, sum fl(b b)) and the
 //      chip's (sum a, sum fl(a a), nulls) are box queries of a 16-byte summed-area table (sat_kernel.hip) and the evaluation
 //      of such a box keeps ONE product stream, sxy = sum fl(a b), instead of three. -------------------------------------------
@@ -467,7 +467,7 @@ struct PxF32i : PxF32 {
     __device__ static __forceinline__ double sat_s(const SatT &q) { return (double)(q.a & ((1ull << kSatNullShiftF) - 1ull)); }
     __device__ static __forceinline__ double sat_ss(const SatT &q) { return (double)q.b; }
     __device__ static __forceinline__ int sat_nulls(const SatT &q) { return (int)(q.a >> kSatNullShiftF); }
-    __device__ static __forceinline__ void sat_win_sums(double &sy, double &syy, const SatT &q, int, int, int) { sy = sat_s(q); syy = sat_ss(q); }
+    __device__ static __forceinline__ void sat_win_sums(double &sy, double &syy, const SatT &q, int, int, int, double sc) { sy = sat_s(q) * sc; syy = sat_ss(q) * (sc * sc); }   // exact: powers of two
     template <int MODE, bool OPQ>
     __device__ static __forceinline__ void task(AccT<Sum> &acc, uint32_t au, uint32_t p01, uint32_t pff, bool static_pad, uint32_t bu, float thr)
     {
@@ -1165,6 +1165,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         if constexpr (P::SAT_CHIP) {
             bad_chip = exc_chip = chip_nulls;                // null <=> DN == 0 for integral DN: both counts (:622, :723)
             SX = (Sum)P::sat_s(chipQ); SXX = (Sum)P::sat_ss(chipQ);
+            if constexpr (!P::INTEGER) { SX = (Sum)((double)SX * sc_chip); SXX = (Sum)((double)SXX * (sc_chip * sc_chip)); }   // f32 planes of scaled integers: back to pixel units (exact)
         } else {
             bad_chip = (int)group_sum<C::LPC>((uint32_t)bad_chip); exc_chip = (int)group_sum<C::LPC>((uint32_t)exc_chip);
             SX = P::template gsum<C::LPC>(SX); SXX = P::template gsum<C::LPC>(SXX);
@@ -1359,8 +1360,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // corrections to n, sx, sxx are zero): the finishing lanes publish one flag per cell of the batch.
             [[maybe_unused]] unsigned char *nzf = reinterpret_cast<unsigned char *>(&qcnt[24]);       // [kSumBatch]
             constexpr bool kNullFlags = C::SPARSE && P::SAT && !MIMC3_SAT_DEFER && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
+            // (pays where a box is a small part of the window -- BASELINE C4: 65^2 of 133^2, many dirty-list boxes hold no null, -1.8 % --
+            //  and costs a barrier per batch where it is not: C2's 81^2 of 113^2, +1 %)
+            const bool flags_on = kNullFlags && 3 * CW * CW <= pt.Dx2 * pt.Dy2;
             if constexpr (kNullFlags) {
-                if (dirty_list && sparse_on) {
+                if (dirty_list && sparse_on && flags_on) {
                     if (tid < nb) nzf[tid] = (unsigned char)((P::SATZ ? cellZ : P::sat_nulls(cellQ)) != 0);
                     __syncthreads();
                 }
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                             for (int k = 0; k < 2; k++) { csy += bv[k]; csyy += (Sum)__umul24(bv[k], bv[k]); }
                         };
                         bool wnull = dirty_list;
-                        if constexpr (kNullFlags) wnull = dirty_list && on && nzf[slot] != 0;
+                        if constexpr (kNullFlags) { if (flags_on) wnull = dirty_list && on && nzf[slot] != 0; }
                         six = wnull;
                         if (wnull) {
                             corr_w(ew);
@@ -1516,7 +1520,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     if (wn_cell) {
                         Sum ty = 0, tyy = 0;
                         const int z = P::SATZ ? cellZ : P::sat_nulls(cellQ);
-                        P::sat_win_sums(ty, tyy, cellQ, z, kb, C::NPX);
+                        P::sat_win_sums(ty, tyy, cellQ, z, kb, C::NPX, sc_win);
                         v[0] = (Store)(uint32_t)(C::NPX - z); v[2] = P::bits(ty); v[4] = P::bits(tyy);
                     }
                 }
@@ -1531,7 +1535,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         const bool sparse_cell = C::SPARSE && sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2));
                         if (sparse_cell || mode == M_FAST) {
                             Sum ty = 0, tyy = 0;
-                            P::sat_win_sums(ty, tyy, cellQ, cellZ, kb, C::NPX);
+                            P::sat_win_sums(ty, tyy, cellQ, cellZ, kb, C::NPX, sc_win);
                             v[2] += P::bits(ty); v[4] += P::bits(tyy);
                         }
                     }
@@ -1542,7 +1546,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 if constexpr (P::SAT && !kAPark) {
                     if (mode == M_FAST) {
                         Sum ty = 0, tyy = 0;
-                        P::sat_win_sums(ty, tyy, cellQ, 0, kb, C::NPX);
+                        P::sat_win_sums(ty, tyy, cellQ, 0, kb, C::NPX, sc_win);
                         v[0] = (Store)NV; v[1] = P::bits(SX); v[2] = P::bits(ty); v[3] = P::bits(SXX); v[4] = P::bits(tyy);
                     }
                 }

@@ -10,9 +10,9 @@ constexpr int kSatSqShift8 = 21, kSatNullShift8 = 50;
 // u16 planes (q < 4096): f(q) = q | q^2 << 25        (sum q < 2^25, sum q^2 < 2^37); nulls in a second u32 table
 constexpr int kSatSqShift16 = 25;
 
-// f32 planes of INTEGRAL DN < 2^18 (16-bit imagery and its integer gradients): the reference's sums are sum (double)b and sum (double)(float)(b * b)
+// f32 planes of INTEGRAL values < 2^20, possibly after a scale by 8 (16-bit imagery, its integer gradients, its Laplacian in 1/8 units): the reference's sums are sum (double)b and sum (double)(float)(b * b)
 // (MIMC_module.c:726-730: the f32 product ROUNDS above 2^24, T1) -- both exact integers in any order.  One 16-byte entry:
-//   a = sum b | nulls << 40   (a box of <= 81^2 pixels: sum b < 2^31, nulls < 2^13),   b = sum fl(b * b)  (< 2^49)
+//   a = sum b | nulls << 40   (a box of <= 81^2 pixels: sum b < 2^33, nulls < 2^13),   b = sum fl(b * b)  (< 2^53: the reference's own f64 sums are exact up to there)
 constexpr int kSatNullShiftF = 40;
 struct Sat2 {
     unsigned long long a, b;
@@ -31,8 +31,8 @@ hipError_t launch_sat_u8(const unsigned char *plane, int Hp, int Wp, unsigned lo
 hipError_t launch_sat_u16(const unsigned short *plane, int Hp, int Wp, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s);
 size_t sat2_bytes(int Hp, int Wp);         // f32 planes: (Hp + 1) x sat_pitch(Wp) x 16; scratch: sat2_scratch_bytes
 size_t sat2_scratch_bytes(int Hp, int Wp);
-hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, Sat2 *S, void *scratch, hipStream_t s);
-// are all pixels integers in [0, 2^18)?  *d_flag |= 1 if not
+hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, int shift /* pixel x 2^shift is the integer */, Sat2 *S, void *scratch, hipStream_t s);
+// *d_flag |= 1 if some pixel is not an integer in [0, 2^20), |= 2 if some pixel x 8 is not
 hipError_t launch_detect_int16(const float *img, size_t n, int *d_flag, hipStream_t s);
 
 // box sum of the w x h pixels whose top-left plane pixel is (x, y): four loads, modular inclusion-exclusion

@@ -27,23 +27,26 @@ namespace {
 
 template <class PX> struct SatF;
 template <> struct SatF<unsigned char> {
-    __device__ static __forceinline__ unsigned long long f(unsigned v)
+    __device__ static __forceinline__ unsigned long long f(unsigned v, float)
     {
         return (unsigned long long)v + ((unsigned long long)(v * v) << kSatSqShift8) + ((unsigned long long)(v == 0u) << kSatNullShift8);
     }
 };
 template <> struct SatF<unsigned short> {
-    __device__ static __forceinline__ unsigned long long f(unsigned v)
+    __device__ static __forceinline__ unsigned long long f(unsigned v, float)
     {
         return (unsigned long long)v + ((unsigned long long)(v * v) << kSatSqShift16);
     }
 };
 
 template <> struct SatF<float> {
-    __device__ static __forceinline__ Sat2 f(float v)
+    // `mul` = 2^s makes the pixel an integer (s = 0: DN; s = 3: the Laplacian's multiples of 1/8): the table holds the sums of the
+    // scaled values, fl((v 2^s)^2) = fl(v^2) 2^2s exactly (a power of two commutes with the rounding), and the kernel scales back
+    __device__ static __forceinline__ Sat2 f(float v, float mul)
     {
-        const float sq = v * v;                                      // the reference's f32 product (rounds above 2^24)
-        return Sat2{(unsigned long long)v + ((unsigned long long)(v == 0.0f) << kSatNullShiftF), (unsigned long long)sq};
+        const float w = v * mul;
+        const float sq = w * w;                                      // the reference's f32 product (rounds above 2^24), scaled
+        return Sat2{(unsigned long long)w + ((unsigned long long)(w == 0.0f) << kSatNullShiftF), (unsigned long long)sq};
     }
 };
 template <class PX> struct SatE { typedef unsigned long long type; };
@@ -65,7 +68,7 @@ __device__ __forceinline__ Sat2 wave_scan(Sat2 v, int lane) { return Sat2{wave_s
 //      (the column pass then adds the rows up in place)
 template <class PX>
 __global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, int Wp, typename SatE<PX>::type *__restrict__ S, int Ws,
-                                                unsigned int *__restrict__ Z, int have_z)
+                                                unsigned int *__restrict__ Z, int have_z, float mul)
 {
     typedef typename SatE<PX>::type E;
     __shared__ E wsum[4];
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, in
     for (int x0 = 0; x0 < Wp; x0 += 256) {
         const int x = x0 + tid;
         const PX v = x < Wp ? row[x] : (PX)1;                       // (positions past the row end are never stored)
-        E s = wave_scan(x < Wp ? SatF<PX>::f(v) : E{}, lane);
+        E s = wave_scan(x < Wp ? SatF<PX>::f(v, mul) : E{}, lane);
         unsigned long long z = have_z ? wave_scan((x < Wp && v == (PX)0) ? 1ull : 0ull, lane) : 0ull;
         if (lane == 63) { wsum[wave] = s; zsum[wave] = z; }
         __syncthreads();
@@ -130,14 +133,14 @@ __global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, 
 constexpr int kSatSeg = 64;
 
 template <class PX>
-hipError_t build(const PX *plane, int Hp, int Wp, typename SatE<PX>::type *S, unsigned int *Z, void *scratch, hipStream_t s)
+hipError_t build(const PX *plane, int Hp, int Wp, typename SatE<PX>::type *S, unsigned int *Z, void *scratch, hipStream_t s, float mul = 1.0f)
 {
     typedef typename SatE<PX>::type E;
     const int Ws = sat_pitch(Wp), rows = Hp + 1, nseg = (Hp + kSatSeg - 1) / kSatSeg;
     hipError_t e = hipMemsetAsync(S, 0, sizeof(E) * (size_t)Ws, s);                  // row 0
     if (e != hipSuccess) return e;
     if (Z && (e = hipMemsetAsync(Z, 0, sizeof(unsigned int) * (size_t)Ws, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(sat_rows<PX>, dim3(Hp), dim3(256), 0, s, plane, Wp, S, Ws, Z, Z ? 1 : 0);
+    hipLaunchKernelGGL(sat_rows<PX>, dim3(Hp), dim3(256), 0, s, plane, Wp, S, Ws, Z, Z ? 1 : 0, mul);
     E *part = static_cast<E *>(scratch);
     const dim3 grid((Ws + 255) / 256, nseg);
     hipLaunchKernelGGL(sat_col_partial<E>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
@@ -162,19 +165,21 @@ size_t sat_scratch_bytes(int Hp, int Wp)
 
 size_t sat2_bytes(int Hp, int Wp) { return sizeof(Sat2) * (size_t)(Hp + 1) * sat_pitch(Wp); }
 size_t sat2_scratch_bytes(int Hp, int Wp) { return sizeof(Sat2) * ((size_t)(Hp + kSatSeg - 1) / kSatSeg) * sat_pitch(Wp); }
-hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, Sat2 *S, void *scratch, hipStream_t s)
+hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, int shift, Sat2 *S, void *scratch, hipStream_t s)
 {
-    return build<float>(plane, Hp, Wp, S, nullptr, scratch, s);
+    return build<float>(plane, Hp, Wp, S, nullptr, scratch, s, (float)(1 << shift));
 }
 
+// bit 0: some pixel is not an integer in [0, 2^20); bit 1: some pixel x 8 is not
 __global__ void detect_int16(const float *img, size_t n, int *flag)
 {
     int f = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = img[i];
-        if (!(v >= 0.0f && v <= 262143.0f && truncf(v) == v)) f = 1;     // NaN fails every comparison
+        const float v = img[i], v8 = v * 8.0f;
+        if (!(v >= 0.0f && v <= 1048575.0f && truncf(v) == v)) f |= 1;     // NaN fails every comparison
+        if (!(v8 >= 0.0f && v8 <= 1048575.0f && truncf(v8) == v8)) f |= 2;
     }
-    if (f) atomicOr(flag, 1);
+    if (f) atomicOr(flag, f);
 }
 hipError_t launch_detect_int16(const float *img, size_t n, int *d_flag, hipStream_t s)
 {
