@@ -325,7 +325,7 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
             "bytes_over_pcie_per_step": int((16 + api.CORRIDOR_BYTES + 12) * n + 4 * 24),
             "identical_to_resident_run": same,
             "what": "mimc3_match_ncc_dlc_cor: per grid point 16 B of (u, v) + 24 B of corridor up, pivot lists made on the device, kernel, 12 B down; "
-                    "four chunks, transfers under the matcher; pair resident, corridors made beforehand (as the csr form's lists are)",
+                    "three chunks, transfers under the matcher; pair resident, corridors made beforehand (as the csr form's lists are)",
             "with_host_corridors_inside": {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3,
                                            "what": "mimc3_match_ncc_dlc_geo: + atan2 / cos / sin of every point on the host threads inside the step"},
             "csr_upload_form": {"value": n / dt_csr, "ms_per_step": dt_csr * 1e3,
