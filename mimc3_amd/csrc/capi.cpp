@@ -272,6 +272,15 @@ extern "C" void mimc3_ctx_destroy(mimc3_ctx *c)
 
 // Build the zero-bordered u8 planes and prove (on the device) that both images are 8-bit integral.
 // Runs once per image pair; the CLI then reuses the pair for 8 matcher passes (MIMC_main.c:261-300).
+// what the tables of a context's planes cover: the whole zero-bordered plane (windows hang over the image edge), or -- chip
+// atlases of the control-point stage, whose full-square search areas stay inside a tile -- the image area alone
+static mimc3::SatRegion table_region(const mimc3_ctx *c)
+{
+    const int pad = mimc3::kU8Pad;
+    if (c->child) return mimc3::SatRegion{pad, pad, c->W, c->H};
+    return mimc3::SatRegion{0, 0, c->Wp, c->H + 2 * pad};
+}
+
 // The summed-area tables of the u8 planes: built once per image pair, right behind the planes (enqueued on the context's stream).
 static int build_u8_tables(mimc3_ctx *c)
 {
@@ -279,8 +288,8 @@ static int build_u8_tables(mimc3_ctx *c)
     HIP_TRY(c->sat0.reserve(mimc3::sat_bytes(Hp, c->Wp)));
     HIP_TRY(c->sat1.reserve(mimc3::sat_bytes(Hp, c->Wp)));
     HIP_TRY(c->sat_tmp.reserve(mimc3::sat_scratch_bytes(Hp, c->Wp)));
-    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl0.p), Hp, c->Wp, static_cast<unsigned long long *>(c->sat0.p), c->sat_tmp.p, c->stream));
-    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl1.p), Hp, c->Wp, static_cast<unsigned long long *>(c->sat1.p), c->sat_tmp.p, c->stream));
+    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl0.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->sat0.p), c->sat_tmp.p, c->stream));
+    HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl1.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->sat1.p), c->sat_tmp.p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));      // matcher calls may come in on any stream
     return 0;
 }
@@ -294,9 +303,9 @@ static int build_u16_tables(mimc3_ctx *c, hipStream_t s)
     HIP_TRY(c->hsz0.reserve(mimc3::sat_null_bytes(Hp, c->Wp)));
     HIP_TRY(c->hsz1.reserve(mimc3::sat_null_bytes(Hp, c->Wp)));
     HIP_TRY(c->sat_tmp.reserve(mimc3::sat_scratch_bytes(Hp, c->Wp)));
-    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl0.p), Hp, c->Wp, static_cast<unsigned long long *>(c->hsat0.p),
+    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl0.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->hsat0.p),
                                   static_cast<unsigned int *>(c->hsz0.p), c->sat_tmp.p, s));
-    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl1.p), Hp, c->Wp, static_cast<unsigned long long *>(c->hsat1.p),
+    HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl1.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->hsat1.p),
                                   static_cast<unsigned int *>(c->hsz1.p), c->sat_tmp.p, s));
     return 0;
 }
@@ -517,8 +526,8 @@ static int build_f32_planes(mimc3_ctx *c, hipStream_t s)
             HIP_TRY(c->fsat0.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
             HIP_TRY(c->fsat1.reserve(mimc3::sat2_bytes(Hp, c->Wp)));
             HIP_TRY(c->sat_tmp.reserve(mimc3::sat2_scratch_bytes(Hp, c->Wp)));
-            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl0.p), Hp, c->Wp, s0, static_cast<mimc3::Sat2 *>(c->fsat0.p), c->sat_tmp.p, s));
-            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl1.p), Hp, c->Wp, s1, static_cast<mimc3::Sat2 *>(c->fsat1.p), c->sat_tmp.p, s));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl0.p), c->Wp, table_region(c), s0, static_cast<mimc3::Sat2 *>(c->fsat0.p), c->sat_tmp.p, s));
+            HIP_TRY(mimc3::launch_sat_f32i(static_cast<const float *>(c->fpl1.p), c->Wp, table_region(c), s1, static_cast<mimc3::Sat2 *>(c->fsat1.p), c->sat_tmp.p, s));
             c->f32i_ok = true;
         }
     }
@@ -534,6 +543,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_dev: bad argument");
     if (ocw < 1) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_dev: ocw must be >= 1");
     if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_dev: images not set");
+    if (c->child && c->win_half <= 0) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_dev: a chip-atlas context only matches full-square search areas");   // (its tables cover the image area only)
     HIP_TRY(hipSetDevice(c->device));
     mimc3::MatchArgs a{};
     a.i0 = c->d_i0; a.i1 = c->d_i1; a.H = c->H; a.W = c->W;

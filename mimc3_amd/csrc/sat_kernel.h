@@ -26,12 +26,17 @@ static inline int sat_pitch(int Wp) { return Wp + 1; }
 size_t sat_bytes(int Hp, int Wp);          // (Hp + 1) x sat_pitch(Wp) x 8
 size_t sat_null_bytes(int Hp, int Wp);     // u16 planes only: (Hp + 1) x sat_pitch(Wp) x 4
 size_t sat_scratch_bytes(int Hp, int Wp);  // column-pass partial sums
-// Enqueue the table build for a plane of Hp rows x Wp pixels (the whole zero-bordered plane) on `s`.
-hipError_t launch_sat_u8(const unsigned char *plane, int Hp, int Wp, unsigned long long *S, void *scratch, hipStream_t s);
-hipError_t launch_sat_u16(const unsigned short *plane, int Hp, int Wp, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s);
+// The part of a plane a table covers: x0 <= x < x0 + w, y0 <= y < y0 + h (plane pixels).  Box queries are valid for boxes inside it
+// (the prefix sums start at the region's origin: a box sum is a difference of four entries, any common origin serves).  The
+// whole zero-bordered plane for ordinary pairs; the image area alone for the control-point stage's chip atlases, whose search
+// areas never leave a tile (their planes are mostly border).
+struct SatRegion { int x0, y0, w, h; };
+// Enqueue the table build on `s`.  `Wp` = the plane's pitch in pixels; tables keep the full plane's geometry (sat_pitch(Wp)).
+hipError_t launch_sat_u8(const unsigned char *plane, int Wp, SatRegion rg, unsigned long long *S, void *scratch, hipStream_t s);
+hipError_t launch_sat_u16(const unsigned short *plane, int Wp, SatRegion rg, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s);
 size_t sat2_bytes(int Hp, int Wp);         // f32 planes: (Hp + 1) x sat_pitch(Wp) x 16; scratch: sat2_scratch_bytes
 size_t sat2_scratch_bytes(int Hp, int Wp);
-hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, int shift /* pixel x 2^shift is the integer */, Sat2 *S, void *scratch, hipStream_t s);
+hipError_t launch_sat_f32i(const float *plane, int Wp, SatRegion rg, int shift /* pixel x 2^shift is the integer */, Sat2 *S, void *scratch, hipStream_t s);
 // *d_flag |= 1 if some pixel is not an integer in [0, 2^20), |= 2 if some pixel x 8 is not
 hipError_t launch_detect_int16(const float *img, size_t n, int *d_flag, hipStream_t s);
 

@@ -67,14 +67,14 @@ __device__ __forceinline__ Sat2 wave_scan(Sat2 v, int lane) { return Sat2{wave_s
 // ---- pass A: row prefix.  One workgroup per plane row y: S[y+1][x+1] = sum_{x' <= x} f(P[y][x']), S[y+1][0] = 0.
 //      (the column pass then adds the rows up in place)
 template <class PX>
-__global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, int Wp, typename SatE<PX>::type *__restrict__ S, int Ws,
+__global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, int pitch, int Wp, typename SatE<PX>::type *__restrict__ S, int Ws,
                                                 unsigned int *__restrict__ Z, int have_z, float mul)
 {
     typedef typename SatE<PX>::type E;
     __shared__ E wsum[4];
     __shared__ unsigned long long zsum[4];
     const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const PX *row = plane + (size_t)y * Wp;
+    const PX *row = plane + (size_t)y * pitch;
     E *out = S + (size_t)(y + 1) * Ws;
     unsigned int *zout = have_z ? Z + (size_t)(y + 1) * Ws : nullptr;
     E carry{};
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void sat_rows(const PX *__restrict__ plane, in
 
 // ---- pass B: per column x and row segment: sum of the segment's row-prefix values
 template <class T>
-__global__ __launch_bounds__(256) void sat_col_partial(const T *__restrict__ S, int Ws, int rows, int seg, T *__restrict__ part)
+__global__ __launch_bounds__(256) void sat_col_partial(const T *__restrict__ S, int Ws, int ncol, int rows, int seg, T *__restrict__ part)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
-    if (x >= Ws) return;
+    if (x >= ncol) return;
     const int r0 = 1 + sg * seg, r1 = min(rows, r0 + seg);          // rows 1 .. rows-1 carry data (row 0 is the zero row)
     T acc{};
     for (int r = r0; r < r1; r++) acc += S[(size_t)r * Ws + x];
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256) void sat_col_partial(const T *__restrict__ S, 
 }
 // ---- pass C: column prefix inside each segment, started from the sum of the segments above
 template <class T>
-__global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, int rows, int seg, const T *__restrict__ part)
+__global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, int ncol, int rows, int seg, const T *__restrict__ part)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
-    if (x >= Ws) return;
+    if (x >= ncol) return;
     T run{};
     for (int s = 0; s < sg; s++) run += part[(size_t)s * Ws + x];
     const int r0 = 1 + sg * seg, r1 = min(rows, r0 + seg);
@@ -132,23 +132,30 @@ __global__ __launch_bounds__(256) void sat_col_apply(T *__restrict__ S, int Ws, 
 
 constexpr int kSatSeg = 64;
 
+// The table of the region [x0, x0 + w) x [y0, y0 + h) of the plane (pitch `Wp_full` pixels; the table keeps the full plane's
+// geometry): entries S[y][x] for y0 <= y <= y0 + h, x0 <= x <= x0 + w are prefix sums from (x0, y0) -- a box query is a
+// difference of four of them, so any origin serves as long as the box lies inside the region.
 template <class PX>
-hipError_t build(const PX *plane, int Hp, int Wp, typename SatE<PX>::type *S, unsigned int *Z, void *scratch, hipStream_t s, float mul = 1.0f)
+hipError_t build(const PX *plane_full, int Wp_full, SatRegion rg, typename SatE<PX>::type *S_full, unsigned int *Z_full, void *scratch, hipStream_t s, float mul = 1.0f)
 {
     typedef typename SatE<PX>::type E;
-    const int Ws = sat_pitch(Wp), rows = Hp + 1, nseg = (Hp + kSatSeg - 1) / kSatSeg;
-    hipError_t e = hipMemsetAsync(S, 0, sizeof(E) * (size_t)Ws, s);                  // row 0
+    const int Ws = sat_pitch(Wp_full), Hp = rg.h, Wp = rg.w;
+    const PX *plane = plane_full + (size_t)rg.y0 * Wp_full + rg.x0;
+    E *S = S_full + (size_t)rg.y0 * Ws + rg.x0;
+    unsigned int *Z = Z_full ? Z_full + (size_t)rg.y0 * Ws + rg.x0 : nullptr;
+    const int rows = Hp + 1, nseg = (Hp + kSatSeg - 1) / kSatSeg;
+    hipError_t e = hipMemsetAsync(S, 0, sizeof(E) * (size_t)(Wp + 1), s);                  // row 0 of the region
     if (e != hipSuccess) return e;
-    if (Z && (e = hipMemsetAsync(Z, 0, sizeof(unsigned int) * (size_t)Ws, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(sat_rows<PX>, dim3(Hp), dim3(256), 0, s, plane, Wp, S, Ws, Z, Z ? 1 : 0, mul);
+    if (Z && (e = hipMemsetAsync(Z, 0, sizeof(unsigned int) * (size_t)(Wp + 1), s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(sat_rows<PX>, dim3(Hp), dim3(256), 0, s, plane, Wp_full, Wp, S, Ws, Z, Z ? 1 : 0, mul);
     E *part = static_cast<E *>(scratch);
-    const dim3 grid((Ws + 255) / 256, nseg);
-    hipLaunchKernelGGL(sat_col_partial<E>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
-    hipLaunchKernelGGL(sat_col_apply<E>, grid, dim3(256), 0, s, S, Ws, rows, kSatSeg, part);
+    const dim3 grid((Wp + 1 + 255) / 256, nseg);
+    hipLaunchKernelGGL(sat_col_partial<E>, grid, dim3(256), 0, s, S, Ws, Wp + 1, rows, kSatSeg, part);
+    hipLaunchKernelGGL(sat_col_apply<E>, grid, dim3(256), 0, s, S, Ws, Wp + 1, rows, kSatSeg, part);
     if (Z) {
         unsigned int *zp = reinterpret_cast<unsigned int *>(part + (size_t)nseg * Ws);
-        hipLaunchKernelGGL(sat_col_partial<unsigned int>, grid, dim3(256), 0, s, Z, Ws, rows, kSatSeg, zp);
-        hipLaunchKernelGGL(sat_col_apply<unsigned int>, grid, dim3(256), 0, s, Z, Ws, rows, kSatSeg, zp);
+        hipLaunchKernelGGL(sat_col_partial<unsigned int>, grid, dim3(256), 0, s, Z, Ws, Wp + 1, rows, kSatSeg, zp);
+        hipLaunchKernelGGL(sat_col_apply<unsigned int>, grid, dim3(256), 0, s, Z, Ws, Wp + 1, rows, kSatSeg, zp);
     }
     return hipGetLastError();
 }
@@ -165,9 +172,9 @@ size_t sat_scratch_bytes(int Hp, int Wp)
 
 size_t sat2_bytes(int Hp, int Wp) { return sizeof(Sat2) * (size_t)(Hp + 1) * sat_pitch(Wp); }
 size_t sat2_scratch_bytes(int Hp, int Wp) { return sizeof(Sat2) * ((size_t)(Hp + kSatSeg - 1) / kSatSeg) * sat_pitch(Wp); }
-hipError_t launch_sat_f32i(const float *plane, int Hp, int Wp, int shift, Sat2 *S, void *scratch, hipStream_t s)
+hipError_t launch_sat_f32i(const float *plane, int Wp, SatRegion rg, int shift, Sat2 *S, void *scratch, hipStream_t s)
 {
-    return build<float>(plane, Hp, Wp, S, nullptr, scratch, s, (float)(1 << shift));
+    return build<float>(plane, Wp, rg, S, nullptr, scratch, s, (float)(1 << shift));
 }
 
 // bit 0: some pixel is not an integer in [0, 2^20); bit 1: some pixel x 8 is not
@@ -187,13 +194,13 @@ hipError_t launch_detect_int16(const float *img, size_t n, int *d_flag, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_sat_u8(const unsigned char *plane, int Hp, int Wp, unsigned long long *S, void *scratch, hipStream_t s)
+hipError_t launch_sat_u8(const unsigned char *plane, int Wp, SatRegion rg, unsigned long long *S, void *scratch, hipStream_t s)
 {
-    return build<unsigned char>(plane, Hp, Wp, S, nullptr, scratch, s);
+    return build<unsigned char>(plane, Wp, rg, S, nullptr, scratch, s);
 }
-hipError_t launch_sat_u16(const unsigned short *plane, int Hp, int Wp, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s)
+hipError_t launch_sat_u16(const unsigned short *plane, int Wp, SatRegion rg, unsigned long long *S, unsigned int *Z, void *scratch, hipStream_t s)
 {
-    return build<unsigned short>(plane, Hp, Wp, S, Z, scratch, s);
+    return build<unsigned short>(plane, Wp, rg, S, Z, scratch, s);
 }
 
 }  // namespace mimc3
