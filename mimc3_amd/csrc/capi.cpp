@@ -64,6 +64,7 @@ struct mimc3_ctx {
     DevBuf pl0, pl1, flag;              // zero-bordered u8 planes (exact-integer path) + "not 8-bit" flag
     DevBuf sat0, sat1, sat_tmp;         // packed summed-area tables of pl0 / pl1 (sum b | sum b^2 | nulls; sat_kernel.hip), built with the planes
     DevBuf hsat0, hsat1, hsz0, hsz1;    // the same for the u16 planes hpl0 / hpl1: sum q | sum q^2, and the null counts
+    bool sat_u8_ok = false, sat_u16_ok = false;   // tables hold the CURRENT planes (chip-atlas contexts build them only if a call needs them)
     DevBuf ovf;                         // [0] count, [1..] indices of points the u8 kernel handed back
     DevBuf fail;                        // [0] count, [1..] points the offset-u8 kernel handed to the u16 kernel
     bool u8o_ok = false;                // integer (shift 0) u16 planes whose local range mostly fits 8 bits: try PxU8o first
@@ -291,6 +292,7 @@ static int build_u8_tables(mimc3_ctx *c)
     HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl0.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->sat0.p), c->sat_tmp.p, c->stream));
     HIP_TRY(mimc3::launch_sat_u8(static_cast<const unsigned char *>(c->pl1.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->sat1.p), c->sat_tmp.p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));      // matcher calls may come in on any stream
+    c->sat_u8_ok = true;
     return 0;
 }
 
@@ -307,6 +309,7 @@ static int build_u16_tables(mimc3_ctx *c, hipStream_t s)
                                   static_cast<unsigned int *>(c->hsz0.p), c->sat_tmp.p, s));
     HIP_TRY(mimc3::launch_sat_u16(static_cast<const unsigned short *>(c->hpl1.p), c->Wp, table_region(c), static_cast<unsigned long long *>(c->hsat1.p),
                                   static_cast<unsigned int *>(c->hsz1.p), c->sat_tmp.p, s));
+    c->sat_u16_ok = true;
     return 0;
 }
 
@@ -314,12 +317,13 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
 {
     c->u8_ok = false;
     c->fplanes_ok = false;
+    c->sat_u8_ok = false; c->sat_u16_ok = false;
     const int pad = mimc3::kU8Pad;
     c->Wp = (c->W + 2 * pad + 3) & ~3;
     const size_t bytes = (size_t)(c->H + 2 * pad) * c->Wp;
     if (planes_built) {                 // raw 8-bit DN was widened straight into the planes (mimc3_ctx_set_images_u8)
         c->u8_ok = true; c->u16_ok = false; c->hpl_valid = false; c->u8o_ok = false;
-        return build_u8_tables(c);
+        return c->child ? 0 : build_u8_tables(c);
     }
     HIP_TRY(c->pl0.reserve(bytes));
     HIP_TRY(c->pl1.reserve(bytes));
@@ -338,7 +342,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
     c->u16_ok = false;
     c->hpl_valid = false;
     c->u8o_ok = false;
-    if (c->u8_ok) RC_TRY(build_u8_tables(c));
+    if (c->u8_ok && !c->child) RC_TRY(build_u8_tables(c));   // (a chip-atlas context: only if a call needs them, see mimc3_match_ncc_dlc_dev)
     if (!c->u8_ok) {
         // not 8-bit: is the pair "scaled integer" (12-bit DN, or what GMA_float_conv2 makes of 8-bit images:
         // integers / multiples of 1/8)?  Then the exact u16 kernel applies.
@@ -359,7 +363,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
             HIP_TRY(hipMemsetAsync(c->hpl1.p, 0, hb, c->stream));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i0, c->H, c->W, static_cast<unsigned short *>(c->hpl0.p), c->Wp, pad, s0, c->stream));
             HIP_TRY(mimc3::launch_prep_u16(c->d_i1, c->H, c->W, static_cast<unsigned short *>(c->hpl1.p), c->Wp, pad, s1, c->stream));
-            RC_TRY(build_u16_tables(c, c->stream));
+            if (!c->child) RC_TRY(build_u16_tables(c, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->shift0 = s0; c->shift1 = s1; c->u16_ok = true; c->hpl_valid = true;
             // 9-bit integers (gradients of 8-bit images): does the LOCAL range fit 8 bits almost everywhere?  Then the
@@ -510,7 +514,7 @@ static int build_f32_planes(mimc3_ctx *c, hipStream_t s)
     // 16-bit DN and its filtered forms (every pixel, x 1 or x 8, an integer in [0, 2^20)): the f64 sums of the reference are exact integers in any order, and the
     // planes get summed-area tables like the integer planes (one read-back per image pair)
     c->f32i_ok = false;
-    if (!getenv("MIMC3_NO_F32_TABLES")) {
+    if (!getenv("MIMC3_NO_F32_TABLES") && !c->child) {     // (not for the control-point stage's chip atlases: a few hundred latency-bound points)
         int fl[2] = {3, 3};
         HIP_TRY(c->flag.reserve(2 * sizeof(int)));
         HIP_TRY(hipMemsetAsync(c->flag.p, 0, 2 * sizeof(int), s));
@@ -606,6 +610,10 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         HIP_TRY(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
         u.ovf_count = static_cast<int32_t *>(ovf.p);
         u.ovf_list = u.ovf_count + 1;
+        // the many-pivot kernel forms (the control-point stage's 21x21 pivot set on its two chip sizes) read no tables
+        const bool tables_needed = !(max_npiv > 64 && (ocw == 15 || ocw == 30));
+        if (want_u8 && tables_needed && !c->sat_u8_ok) RC_TRY(build_u8_tables(c));
+        if (want_u16 && tables_needed && !c->sat_u16_ok) { RC_TRY(build_u16_tables(c, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
         if (want_u8) {
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
             u.sat0 = c->sat0.p; u.sat1 = c->sat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);

@@ -672,6 +672,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 {
     typedef typename C::P P;
     typedef typename P::Sum Sum;
+    // summed-area tables: every policy that has them, except the many-pivot forms -- those only serve the control-point stage, whose
+    // chip atlases (a few hundred latency-bound points per match, planes that are mostly border) are not worth building tables for
+    constexpr bool kSat = P::SAT && !C::MANYP, kSatChip = P::SAT_CHIP && kSat, kSatZ = P::SATZ && kSat;
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -726,16 +729,16 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     const uint32_t *satz_win = nullptr;
     SatT chipQ{};
     int chip_nulls = 0, win_nulls = 0;
-    if constexpr (P::SAT) {
+    if constexpr (kSat) {
         sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
         sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
         satz_win = reinterpret_cast<const uint32_t *>(p.swap ? p.satz0 : p.satz1);
         const int wc = 2 * pt.dx2 + (full_win ? 1 : 0), wr = 2 * pt.dy2 + (full_win ? 1 : 0);          // the written area (:869-886)
-        if constexpr (P::SATZ) win_nulls = (int)sat_box(satz_win, p.sat_ws, wu0, wv0, wc, wr);
+        if constexpr (kSatZ) win_nulls = (int)sat_box(satz_win, p.sat_ws, wu0, wv0, wc, wr);
         else win_nulls = P::sat_nulls(sat_box(sat_win, p.sat_ws, wu0, wv0, wc, wr));
-        if constexpr (P::SAT_CHIP) {
+        if constexpr (kSatChip) {
             chipQ = sat_box(sat_chip, p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
-            if constexpr (P::SATZ) chip_nulls = (int)sat_box(reinterpret_cast<const uint32_t *>(p.swap ? p.satz1 : p.satz0), p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
+            if constexpr (kSatZ) chip_nulls = (int)sat_box(reinterpret_cast<const uint32_t *>(p.swap ? p.satz1 : p.satz0), p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);
             else chip_nulls = P::sat_nulls(chipQ);
         }
     }
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             };
             int rb = r0;
-            if (P::SAT && win_nulls == 0) {
+            if (kSat && win_nulls == 0) {
                 for (; rb + (KB - 1) * rstep < wrows; rb += KB * rstep) batch(std::false_type{}, std::true_type{}, rb);
                 if (rb < wrows) batch(std::true_type{}, std::true_type{}, rb);
             } else {
@@ -1077,11 +1080,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 uint32_t a = (P::G > 1) ? alignb(g[j + (P::G > 1 ? 1 : 0)], g[j], sa) : g[j];
                 const uint32_t pff = rowok ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
                 a &= pff;
-                if constexpr (P::SAT_CHIP) { }                                                       // counts and sums come from the table
+                if constexpr (kSatChip) { }                                                       // counts and sums come from the table
                 else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);    // the exact counts are taken afterwards, and only then
                 else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
                 A[i][j] = a;
-                if constexpr (!P::SAT_CHIP) P::chip_acc(SX, SXX, a);
+                if constexpr (!kSatChip) P::chip_acc(SX, SXX, a);
                 if constexpr (C::SPARSE) {
                     if ((j % NW) == wave && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;   // every wave holds the whole chip: each writes a share of the copy
                 }
@@ -1096,19 +1099,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             uint32_t a = (P::G > 1) ? alignb(chip_dword(rr, j + (P::G > 1 ? 1 : 0)), g0, sa) : g0;
             const uint32_t pff = on ? ((j == GPR - 1) ? C::LASTFF : 0xffffffffu) : 0u;
             a &= pff;
-            if constexpr (P::SAT_CHIP) { }
+            if constexpr (kSatChip) { }
             else if constexpr (P::INTEGER) chip_susp = chip_susp || P::maybe_excl(a, pff, pt.thr);
             else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
             AT[k] = a;
             toff[k] = rr * pt.PW + 4 * j;
             if (C::FULLTAIL && on && j == GPR - 1) padoff = toff[k];
-            if constexpr (!P::SAT_CHIP) P::chip_acc(SX, SXX, a);
+            if constexpr (!kSatChip) P::chip_acc(SX, SXX, a);
             if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
                 if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
             }
         }
         // (with a table the chip's null count is known: only the sparse-correction configs look at the pixels again, to LIST them)
-        if constexpr (P::SAT_CHIP) chip_susp = C::SPARSE && chip_nulls != 0;
+        if constexpr (kSatChip) chip_susp = C::SPARSE && chip_nulls != 0;
         if (P::INTEGER && chip_susp) {                        // rare: the lane's chip dwords again, counted exactly (and listed)
 #pragma unroll
             for (int i = 0; i < C::RF; i++) {
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     bad_chip += P::nbad(AT[k], pff, pt.thr);
                     const int nzc = P::nexcl(AT[k], pff, pt.thr);
                     exc_chip += nzc;
-                    if constexpr (C::FULLTAIL || (P::SAT && C::SPARSE)) {   // maskless tail tasks (and every XY body): the tail rows' nulls are corrected from the list too
+                    if constexpr (C::FULLTAIL || (kSat && C::SPARSE)) {   // maskless tail tasks (and every XY body): the tail rows' nulls are corrected from the list too
                         if (wave == 0 && on && nzc) {
                             int at = atomicAdd(&qcnt[17], nzc);
                             if (at + nzc > kLcCap) qcnt[18] = 1;
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 }
             }
         }
-        if constexpr (P::SAT_CHIP) {
+        if constexpr (kSatChip) {
             bad_chip = exc_chip = chip_nulls;                // null <=> DN == 0 for integral DN: both counts (:622, :723)
             SX = (Sum)P::sat_s(chipQ); SXX = (Sum)P::sat_ss(chipQ);
             if constexpr (!P::INTEGER) { SX = (Sum)((double)SX * sc_chip); SXX = (Sum)((double)SXX * (sc_chip * sc_chip)); }   // f32 planes of scaled integers: back to pixel units (exact)
@@ -1318,7 +1321,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const bool dirty_list = (mode == M_GENERAL);
         // dirty boxes of a null-free chip, planes with a table: the WN body (three sums) instead of the six-sum GENERAL body --
         // except where a cell of the wave's round touches the never-written last row / column (T4: the table does not know it)
-        const bool wn_ok = P::SAT && P::WN && MIMC3_WN && dirty_list && exc_chip == 0;
+        const bool wn_ok = kSat && (P::WN && kSat) && MIMC3_WN && dirty_list && exc_chip == 0;
         // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
         uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
         if constexpr (C::SPARSE) {
@@ -1334,7 +1337,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         // table cells of the one-wave configs park ONE word (sxy): 64 of them fit where 32 six-word slots do, and the f64 finish
         // then runs on all 64 lanes
         constexpr int kFastBatch = (6 * kSumBatch < MIMC3_FAST_BATCH) ? 6 * kSumBatch : MIMC3_FAST_BATCH;
-        const bool one_word = P::SAT && !kAPark && NT == 64 && mode == M_FAST && kFastBatch > kSumBatch;
+        const bool one_word = kSat && !kAPark && NT == 64 && mode == M_FAST && kFastBatch > kSumBatch;
         const int batch_cells = one_word ? kFastBatch : kSumBatch;
         for (int b0 = 0; b0 < cnt; b0 += batch_cells) {
             const int nb = (cnt - b0) < batch_cells ? (cnt - b0) : batch_cells;
@@ -1343,14 +1346,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // (the four corners stay in registers until the finish: combining them here would wait for the loads right away)
             [[maybe_unused]] SatT cellQ{}, q00{}, q01{}, q10{}, q11{};
             [[maybe_unused]] int cellZ = 0;
-            if constexpr (P::SAT) {
+            if constexpr (kSat) {
                 const bool need = mode == M_FAST || (C::SPARSE && sparse_on) || (dirty_list && wn_ok);
                 if (need && tid < nb) {
                     const uint32_t pk = ids[dir * (b0 + tid)];
                     const SatT *r0 = sat_win + (size_t)(wv0 + (int)((pk >> 8) & 0xffu)) * p.sat_ws + (wu0 + (int)(pk & 0xffu)), *r1 = r0 + (size_t)CW * p.sat_ws;
                     q00 = r0[0]; q01 = r0[CW]; q10 = r1[0]; q11 = r1[CW];
                     if (!MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
-                    if constexpr (P::SATZ) {        // the nulls of a dirty box: n of a WN cell; the offset policy's unit conversion (its unmasked sums count a null as 0, not as -k)
+                    if constexpr (kSatZ) {        // the nulls of a dirty box: n of a WN cell; the offset policy's unit conversion (its unmasked sums count a null as 0, not as -k)
                         if (dirty_list) cellZ = (int)sat_box(satz_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
                     }
                 }
@@ -1359,13 +1362,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // table knows whether it holds a null at all.  Boxes without one skip the walk over the window-null list (their
             // corrections to n, sx, sxx are zero): the finishing lanes publish one flag per cell of the batch.
             [[maybe_unused]] unsigned char *nzf = reinterpret_cast<unsigned char *>(&qcnt[24]);       // [kSumBatch]
-            constexpr bool kNullFlags = C::SPARSE && P::SAT && !MIMC3_SAT_DEFER && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
+            constexpr bool kNullFlags = C::SPARSE && kSat && !MIMC3_SAT_DEFER && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
             // (pays where a box is a small part of the window -- BASELINE C4: 65^2 of 133^2, many dirty-list boxes hold no null, -1.8 % --
             //  and costs a barrier per batch where it is not: C2's 81^2 of 113^2, +1 %)
             const bool flags_on = kNullFlags && 3 * CW * CW <= pt.Dx2 * pt.Dy2;
             if constexpr (kNullFlags) {
                 if (dirty_list && sparse_on && flags_on) {
-                    if (tid < nb) nzf[tid] = (unsigned char)((P::SATZ ? cellZ : P::sat_nulls(cellQ)) != 0);
+                    if (tid < nb) nzf[tid] = (unsigned char)((kSatZ ? cellZ : P::sat_nulls(cellQ)) != 0);
                     __syncthreads();
                 }
             }
@@ -1435,7 +1438,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                         // lane-local, modulo 2^32 / 2^64: the reduced totals are exact.  (The u16 policy's lanes accumulate
                         // 32 bits inside a 64-bit sum, so there the correction is subtracted after the body.)
-                        if constexpr (C::FULLTAIL && !P::SAT) {         // (before the body: its LDS round trip overlaps the row loads)
+                        if constexpr (C::FULLTAIL && !kSat) {         // (before the body: its LDS round trip overlaps the row loads)
                             // the window pixels under the pad bytes of this lane's row-end tail dword leave sy, syy again
                             const int X = pt.sh + cx;
                             const uint32_t sft = (uint32_t)((X & (P::G - 1)) * P::BPP);
@@ -1447,7 +1450,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         if (kFold) { a0.sy = (Sum)0 - csy; a0.syy = (Sum)0 - csyy; }
                         // (with a table the body adds nothing to sy, syy: they leave as the corrections alone, the table's box sums
                         //  -- nulls are zeros in them -- are added in the finish)
-                        acc = eval_round<C, P::SAT ? M_XY : M_FAST, false, C::FULLTAIL>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
+                        acc = eval_round<C, kSat ? M_XY : M_FAST, false, C::FULLTAIL>(W, pt, cx, cy, l, A, AT, toff, a0, CH);
                         if (!kFold) { acc.sy -= csy; acc.syy -= csyy; }
                         acc.n = 0u - cn; acc.sx = (Sum)0 - csx; acc.sxx = (Sum)0 - csxx;      // + the point's constants, in the finish
                         done = true;
@@ -1456,14 +1459,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                 }
                 if (!done) {
-                    if (mode == M_FAST) acc = eval_round<C, P::SAT ? M_XY : M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                    if (mode == M_FAST) acc = eval_round<C, kSat ? M_XY : M_FAST, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     else if (mode == M_CHIPNULL) acc = eval_round<C, M_CHIPNULL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     else {
-                        if constexpr (P::SAT) {
+                        if constexpr (kSat) {
                             const bool t4 = on && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2);
                             wn_round = wn_ok && __ballot(t4) == 0ull;
                         }
-                        if (P::SAT && wn_round) acc = eval_round<C, P::SAT ? M_WN : M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                        if (kSat && wn_round) acc = eval_round<C, kSat ? M_WN : M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                         else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     }
                 }
@@ -1474,7 +1477,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const Sum rsxy = P::template gsum<16>(acc.sxy);
                     if (lead) atomicAdd(&sp[5], P::bits(rsxy));
                     // sy, syy: the body's sums; with a table only the chip-null corrections of a sparse cell (else the table has it all)
-                    if (!P::SAT || (done ? nLc > 0 : (mode != M_FAST && !wn_round))) {
+                    if (!kSat || (done ? nLc > 0 : (mode != M_FAST && !wn_round))) {
                         const Sum rsy = P::template gsum<16>(acc.sy), rsyy = P::template gsum<16>(acc.syy);
                         if (lead) { atomicAdd(&sp[2], P::bits(rsy)); atomicAdd(&sp[4], P::bits(rsyy)); }
                     }
@@ -1487,12 +1490,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                         }
                     }
                 } else {
-                    if (P::SAT && mode == M_FAST) {
+                    if (kSat && mode == M_FAST) {
                         if (on && l == 0) { if (one_word) sums[slot] = P::bits(acc.sxy); else sp[5] = P::bits(acc.sxy); }   // the other five sums are the point's constants and the table's
                     } else {
                         if (mode != M_GENERAL) { acc.n = NV; acc.sx = SX; acc.sxx = SXX; }
                         if (on && l == 0) {
-                            if (P::SAT && wn_round) { sp[1] = P::bits(acc.sx); sp[3] = P::bits(acc.sxx); sp[5] = P::bits(acc.sxy); }
+                            if (kSat && wn_round) { sp[1] = P::bits(acc.sx); sp[3] = P::bits(acc.sxx); sp[5] = P::bits(acc.sxy); }
                             else { sp[0] = (Store)acc.n; sp[1] = P::bits(acc.sx); sp[2] = P::bits(acc.sy); sp[3] = P::bits(acc.sxx); sp[4] = P::bits(acc.syy); sp[5] = P::bits(acc.sxy); }
                         }
                     }
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 // did this cell's round run the WN body?  (the decision was taken per wave and round: no cell of its CPR consecutive
                 // slots touches the T4 row / column; the finishing lanes all sit in wave 0)
                 bool wn_cell = false;
-                if constexpr (P::SAT) {
+                if constexpr (kSat) {
                     if (wn_ok) {
                         const bool t4 = !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2);
                         const unsigned long long tm = __ballot(t4);
@@ -1519,7 +1522,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     }
                     if (wn_cell) {
                         Sum ty = 0, tyy = 0;
-                        const int z = P::SATZ ? cellZ : P::sat_nulls(cellQ);
+                        const int z = kSatZ ? cellZ : P::sat_nulls(cellQ);
                         P::sat_win_sums(ty, tyy, cellQ, z, kb, C::NPX, sc_win);
                         v[0] = (Store)(uint32_t)(C::NPX - z); v[2] = P::bits(ty); v[4] = P::bits(tyy);
                     }
@@ -1529,7 +1532,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const bool dense = dirty_list && !(C::SPARSE && sparse_on && !(!full_win && (cx == pt.csx - 2 || cy == pt.csy - 2)));
                     (void)wn_cell;
                     if (!dense) { v[0] += (Store)NV; v[1] += P::bits(SX); v[3] += P::bits(SXX); }
-                    if constexpr (P::SAT) {
+                    if constexpr (kSat) {
                         // window-side sums from the table: every cell but the dense ones and the masked CHIPNULL bodies of the
                         // configs without null lists (those accumulated sy, syy themselves)
                         const bool sparse_cell = C::SPARSE && sparse_on && !(dirty_list && !full_win && (cx == pt.csx - 2 || cy == pt.csy - 2));
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
 #pragma unroll
                     for (int k = 0; k < 6; k++) sp[k] = 0;                 // the slot is empty for the next batch
                 }
-                if constexpr (P::SAT && !kAPark) {
+                if constexpr (kSat && !kAPark) {
                     if (mode == M_FAST) {
                         Sum ty = 0, tyy = 0;
                         P::sat_win_sums(ty, tyy, cellQ, 0, kb, C::NPX, sc_win);
