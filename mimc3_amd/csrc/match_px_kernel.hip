@@ -43,7 +43,10 @@
 #define MIMC3_NULL_FLAGS 1      // sparse-correction configs: skip the window-null walk of dirty-list boxes that hold no null (table look-up)
 #endif
 #ifndef MIMC3_OPQ_SMALL
-#define MIMC3_OPQ_SMALL 0       // keep the chip-derived masks of the small chips out of registers too
+#define MIMC3_OPQ_SMALL 1       // keep the chip-derived masks of the small chips out of registers too (only chips with nulls derive any: GC mode)
+#endif
+#ifndef MIMC3_GC
+#define MIMC3_GC 1              // six-sum body with compile-time chip masks for null-free chips
 #endif
 #ifndef MIMC3_STAGE_KB
 #define MIMC3_STAGE_KB 8        // window rows a thread fetches before it uses any
@@ -107,7 +110,9 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 //            null-free box are box sums of the IMAGE and are read from the table; only sxy is accumulated here
 //   WN       window nulls in the box, null-free chip, planes with a table: n = pixels - nulls of the box, sy, syy are the
 //            table's (a null is a zero in both sums); sx, sxx (chip pixels over the non-null window pixels) and sxy are accumulated
-enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2, M_XY = 3, M_WN = 4 };
+//   GC       GENERAL for a null-free chip: the chip-side masks are the compile-time pad masks of the row tasks, nothing is
+//            derived from the chip dwords -- so nothing chip-derived has to stay in registers across the evaluation loops
+enum { M_FAST = 0, M_CHIPNULL = 1, M_GENERAL = 2, M_XY = 3, M_WN = 4, M_GC = 5 };
 
 template <class S> struct AccT { uint32_t n; S sx, sy, sxx, syy, sxy; };
 
@@ -172,6 +177,17 @@ struct PxU8 {
             acc.sx = dot4(a, t >> 7, acc.sx);
             acc.sxx = dot4(a & ff_from80(t), a, acc.sxx);
             acc.sxy = dot4(a, bw, acc.sxy);
+            return;
+        }
+        if (MODE == M_GC && static_pad) {     // null-free chip, row task: the chip mask is the pad mask
+            const uint32_t t = nz80(bw);
+            const uint32_t mb01 = t >> 7, mbff = ff_from80(t);
+            acc.n = dot4(pad01, mb01, acc.n);
+            acc.sx = dot4(a, mb01, acc.sx);
+            acc.sy = dot4(pad01, bw, acc.sy);
+            acc.sxy = dot4(a, bw, acc.sxy);
+            acc.sxx = dot4(a & mbff, a, acc.sxx);
+            acc.syy = dot4(padff == 0xffffffffu ? bw : (bw & padff), bw, acc.syy);
             return;
         }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a));
@@ -273,6 +289,18 @@ struct PxU16 {
             acc.sx = dot2(a, t >> 15, (uint32_t)acc.sx);
             acc.sxx = dot2(a & ffff_from8000(t), a, (uint32_t)acc.sxx);
             acc.sxy = dot2(a, bw, (uint32_t)acc.sxy);
+            return;
+        }
+        if (MODE == M_GC && static_pad) {
+            const uint32_t t = nz8000(bw);
+            const uint32_t mb01 = t >> 15, mbff = ffff_from8000(t);
+            const uint32_t p01 = padff & 0x00010001u;
+            acc.n = dot2(p01, mb01, acc.n);
+            acc.sx = dot2(a, mb01, (uint32_t)acc.sx);
+            acc.sy = dot2(p01, bw, (uint32_t)acc.sy);
+            acc.sxy = dot2(a, bw, (uint32_t)acc.sxy);
+            acc.sxx = dot2(a & mbff, a, (uint32_t)acc.sxx);
+            acc.syy = dot2(padff == 0xffffffffu ? bw : (bw & padff), bw, (uint32_t)acc.syy);
             return;
         }
         if (OPQ && !(MODE == M_FAST && static_pad)) asm volatile("" : "+v"(a)); // see PxU8::task: keeps the masks out of registers
@@ -648,7 +676,7 @@ __device__ __forceinline__ AccT<typename C::P::Sum> eval_round(const unsigned ch
     acc.sxy = P::template gsum<C::LPC>(acc.sxy);
     if (MODE != M_XY && MODE != M_WN) { acc.sy = P::template gsum<C::LPC>(acc.sy); acc.syy = P::template gsum<C::LPC>(acc.syy); }
     if (MODE == M_WN) { acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx); }
-    if (MODE == M_GENERAL) {
+    if (MODE == M_GENERAL || MODE == M_GC) {
         acc.n = group_sum<C::LPC>(acc.n); acc.sx = P::template gsum<C::LPC>(acc.sx); acc.sxx = P::template gsum<C::LPC>(acc.sxx);
     }
     return acc;
@@ -1467,6 +1495,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                             wn_round = wn_ok && __ballot(t4) == 0ull;
                         }
                         if (kSat && wn_round) acc = eval_round<C, kSat ? M_WN : M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
+                        else if (MIMC3_GC && exc_chip == 0) acc = eval_round<C, M_GC, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);   // null-free chip: nothing derived from the chip dwords
                         else acc = eval_round<C, M_GENERAL, !kAPark>(W, pt, cx, cy, l, A, AT, toff, AccT<Sum>{0, 0, 0, 0, 0, 0}, CH);
                     }
                 }

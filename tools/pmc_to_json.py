@@ -17,16 +17,26 @@ sys.path.insert(0, ROOT)
 from bench import KERNEL_NAMES, kernel_source_sha16  # noqa: E402
 
 out, config = sys.argv[1], sys.argv[2]
-rnd = sys.argv[3] if len(sys.argv) > 3 else None
+rnd = sys.argv[3] if len(sys.argv) > 3 and "=" not in sys.argv[3] else None
+# occupancy of the headline kernel as launched (rocprofv3's dispatch record does not show dynamic LDS): lds=<bytes> vgpr=<count>
+opts = dict(a.split("=", 1) for a in sys.argv[3:] if "=" in a)
 
-acc = defaultdict(lambda: defaultdict(list))
+# counters of the FULL-SIZE launches only: bench.py's io leg launches the same kernel on chunks of the grid
+rows = []
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
-        for r in csv.DictReader(fh):
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-points = None
+        rows += list(csv.DictReader(fh))
+full_grid = defaultdict(int)
+for r in rows:
+    full_grid[r["Kernel_Name"]] = max(full_grid[r["Kernel_Name"]], int(r["Grid_Size"]))
+acc = defaultdict(lambda: defaultdict(list))
+for r in rows:
+    if int(r["Grid_Size"]) == full_grid[r["Kernel_Name"]]:
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+points, ocw = None, None
 try:
-    points = json.load(open(os.path.join(out, "trace_bench.json")))["config"]["grid_points_rank0"]
+    cfgj = json.load(open(os.path.join(out, "trace_bench.json")))["config"]
+    points, ocw = cfgj["grid_points_rank0"], cfgj.get("ocw")
 except Exception:
     pass
 
@@ -42,7 +52,8 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
                 vg = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count", 0) or 0)
                 by_lds = (160 * 1024 // max(lds, 1)) * wg / 4.0
                 by_vgpr = 512 // max(vg, 1)
-                occupancy[r["Kernel_Name"]] = min(by_lds, by_vgpr, 8)
+                if int(r["LDS_Block_Size"]) > 0:          # (dynamic LDS shows as 0 here: no occupancy from such a record)
+                    occupancy[r["Kernel_Name"]] = min(by_lds, by_vgpr, 8)
             except (KeyError, ValueError):
                 pass
 
@@ -51,11 +62,16 @@ db = json.load(open(path)) if os.path.exists(path) else {}
 db.setdefault(config, {})
 for kn, cs in acc.items():
     key = None
-    for short in KERNEL_NAMES.values():
+    for short in list(KERNEL_NAMES.values()) + ["match_ncc_dlc_px<PxF32i>"]:
         tag = short.replace("match_ncc_dlc_px<", "").rstrip(">")
         if ("match_ncc_dlc_px" in kn and f"PxCfg<mimc3::{tag}," in kn.replace(" ", "")) or (short == "match_ncc_dlc_f32" and "match_ncc_dlc_f32" in kn):
             key = short
     if key is None or "SQ_WAVES" not in cs:
+        continue
+    # the bench line's kernels are the config's chip size in their regular (not many-pivot) form; the `program` leg launches others
+    import re
+    m = re.search(r"PxCfg<mimc3::(\w+),(\d+),(\d+),(\d+),(\d+),(true|false),(true|false)", kn.replace(" ", ""))
+    if ocw is not None and m and (int(m.group(2)) != int(ocw) or m.group(7) == "true"):
         continue
     mean = {c: sum(v) / len(v) for c, v in cs.items()}
     waves = mean["SQ_WAVES"]
@@ -74,6 +90,9 @@ for kn, cs in acc.items():
     # resident time in which it has a VALU instruction executing; times the waves resident per SIMD (the occupancy the LDS carve
     # and the register count allow, from the dispatch record) it is the fraction of time the SIMD's VALU is busy
     occ = occupancy.get(kn)
+    if key == KERNEL_NAMES["u8_exact"] and "lds" in opts:
+        lds = (int(opts["lds"]) + 255) // 256 * 256
+        occ = min((160 * 1024 // lds) * nw / 4.0, 512 // int(opts.get("vgpr", 128)))
     if "SQ_ACTIVE_INST_VALU" in mean and "SQ_WAVE_CYCLES" in mean:
         e["valu_active_share_of_wave_time"] = mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_WAVE_CYCLES"]
         if occ:

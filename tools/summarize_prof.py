@@ -30,6 +30,18 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     by = defaultdict(list)
     for r in rows:
         by[r["Kernel_Name"]].append(r)
+    # the matcher kernels by launch size: bench.py's io leg launches the headline kernel on CHUNKS of the grid too, so the
+    # per-name average above mixes sizes -- the full-size launches are the ones `roofline.kernel_ms` times
+    print("\n## matcher launches by grid size (kernel trace)")
+    for k, v in by.items():
+        if "match_ncc_dlc" not in k:
+            continue
+        sizes = defaultdict(list)
+        for r in v:
+            sizes[int(r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for g in sorted(sizes, reverse=True):
+            d = sizes[g]
+            print("  %-44.44s grid=%-9d calls=%4d avg_ns=%12.1f min_ns=%10d max_ns=%10d" % (short(k), g, len(d), sum(d) / len(d), min(d), max(d)))
     print("\n## dispatch resources (first dispatch of each kernel)")
     for k, v in by.items():
         r = v[0]
