@@ -540,7 +540,11 @@ struct PxCfg {
     static constexpr uint32_t LASTFF = P::lowmask_c(LASTN);
     static constexpr uint32_t LAST01 = LASTFF & 0x01010101u;
     static constexpr int CPR = 64 / LPC;                     // cells per evaluation round
-    static constexpr bool OPQ = LPC_ >= 64 || MIMC3_OPQ_SMALL;   // big chips: keep chip-derived masks out of registers (see PxU8::task)
+    // big chips: keep chip-derived masks out of registers (see PxU8::task).  Small chips: where the hoisted masks made the kernel
+    // spill -- measured, same box, with / without: u8 ocw 16 3.10 / 3.22 ms, d/dx ocw 15 4.17 / 4.27; where it did not spill the
+    // hoisted masks stay (u8 ocw 7 2.33 / 2.28, ocw 15 3.25 / 3.14 -- eight mask-deriving tail tasks --, Laplacian ocw 15 6.21 / 6.04)
+    static constexpr bool kOpqSmall = MIMC3_OPQ_SMALL && ((std::is_same<P_, PxU8>::value && OCW_ == 16) || (std::is_same<P_, PxU8o>::value && (OCW_ == 15 || OCW_ == 16)));
+    static constexpr bool OPQ = LPC_ >= 64 || kOpqSmall;
     // Big chips with exact integer sums: a cell whose box (or whose chip) holds null pixels is evaluated as the FAST body
     // (3 dot products per dword) plus CORRECTIONS summed over short lists of the null pixels -- window nulls take chip
     // values out of n, sx, sxx; chip nulls take window values out of sy, syy -- instead of the six-sum GENERAL body
