@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
-KERNEL_NAMES = {"u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dlc_px<PxF32>", "u16_scaled": "match_ncc_dlc_px<PxU16>",
+KERNEL_NAMES = {"u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dlc_px<PxF32i>",     # (PxF32i: the tiled f32 kernel on integral pixels; PxF32 otherwise) "u16_scaled": "match_ncc_dlc_px<PxU16>",
                 "u8_offset": "match_ncc_dlc_px<PxU8o>", "general_f32": "match_ncc_dlc_f32"}
 DTYPES = {"u8_exact": "u8", "u16_scaled": "u16", "u8_offset": "u8"}
 
@@ -258,7 +258,8 @@ def main():
             rf["traffic"] = tr["bytes"]
             rf["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; measured in separate --pmc passes, not in this run)"
             # SURVEY 8(d)'s secondary bounds: the kernel is VALU-issue-bound, not HBM-bound (traffic << algorithmic bytes)
-            for k in ("valu_per_point", "salu_per_point", "lds_per_point", "valu_busy", "lds_active_frac"):
+            for k in ("valu_per_point", "salu_per_point", "lds_per_point", "valu_busy", "waves_per_simd", "wait_share_of_wave_time",
+                      "issue_stall_share_of_wave_time", "issuing_share_of_wave_time"):
                 if k in tr:
                     rf[k] = tr[k]
             if "lds_per_point" in tr and kern_ms > 0:

@@ -100,8 +100,9 @@ for kn, cs in acc.items():
             e["valu_busy"] = min(1.0, e["valu_active_share_of_wave_time"] * occ)
     if "SQ_LDS_IDX_ACTIVE" in mean and "SQ_WAVE_CYCLES" in mean:
         e["lds_active_share_of_wave_time"] = mean["SQ_LDS_IDX_ACTIVE"] / mean["SQ_WAVE_CYCLES"]
-        if occ:
-            e["lds_active_frac"] = min(1.0, e["lds_active_share_of_wave_time"] * occ * 4)   # one LDS per CU = 4 SIMDs
+    for c, k in (("SQ_WAIT_ANY", "wait_share_of_wave_time"), ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_time"), ("SQ_ACTIVE_INST_ANY", "issuing_share_of_wave_time")):
+        if c in mean and "SQ_WAVE_CYCLES" in mean:
+            e[k] = mean[c] / mean["SQ_WAVE_CYCLES"]
     db[config][key] = {**db[config].get(key, {}), **e}
     print(key, json.dumps(e))
 json.dump(db, open(path, "w"), indent=2)
