@@ -48,9 +48,19 @@ __global__ __launch_bounds__(256) void pivot_count(const double *__restrict__ xy
         mn = max(mn, __shfl_xor(mn, o, 64)); au = max(au, __shfl_xor(au, o, 64)); av = max(av, __shfl_xor(av, o, 64));
         zero |= __shfl_xor(zero, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&ext[0], mn); atomicMax(&ext[1], au); atomicMax(&ext[2], av);
-        if (zero) atomicOr(&ext[3], 1);
+    // block maxima through LDS, then at most one atomic per block and word -- and none where the word already holds the value
+    // (every wave hitting four global words directly is thousands of same-address atomics, which serialise)
+    __shared__ int smx[4][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smx[0][wv] = mn; smx[1][wv] = au; smx[2][wv] = av; smx[3][wv] = zero; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        int v = smx[k][0];
+        for (int w = 1; w < 4; w++) v = k == 3 ? (v | smx[k][w]) : max(v, smx[k][w]);
+        if (v > __hip_atomic_load(&ext[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (k == 3) atomicOr(&ext[3], 1); else atomicMax(&ext[k], v);
+        }
     }
 }
 

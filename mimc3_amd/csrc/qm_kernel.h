@@ -6,6 +6,8 @@
 namespace mimc3 {
 
 constexpr int kQmThreads = 128;
+constexpr int kQmFinishThreads = 1024;
+constexpr int kQmMaskWords = 8;        // mismatch bits of up to 256 stacked masks
 constexpr int kQmFlagWords = 16;
 enum { kQmAny = 0, kQmDone = 1, kQmSweeps = 2, kQmSkipped = 3, kQmTicket = 4 };
 constexpr int kQmLaunchesPerSweep = 2;

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(kQmThreads) void qm_init(QmArgs a)
         a.flags[kQmAny] = 0; a.flags[kQmDone] = 0; a.flags[kQmSweeps] = 0;
         a.flags[kQmSkipped] = 0; a.flags[kQmTicket] = 0;
     }
-    if (i < a.max_sweeps + 2) a.diff[i] = 0;
     if (i >= a.N) return;
     const int id = a.dpf[i];
     unsigned char m = 0;
@@ -166,14 +165,20 @@ __global__ __launch_bounds__(kQmThreads) void qm_sweep(QmArgs a, int sweep)
 
 // Second (and last) launch of a sweep: the Jacobi commit (:2218-2233), the comparison of the next mask with every earlier mask
 // of the stack ("fluctuation", :2237-2261) and -- by the block that retires last -- the termination logic of the while loop
-// (:2077, :2263-2286).  The commit and the compare are per grid point; the decision needs every block's compare result:
-// waves OR their mismatch bits (bit s = "the next mask differs from mask s somewhere in this wave") into packed words with
-// device-scope atomics, a ticket counts retired blocks, and the last one reads the words back with atomic loads.
-__global__ __launch_bounds__(kQmThreads) void qm_finish_sweep(QmArgs a, int sweep)
+// (:2077, :2263-2286).  The commit and the compare are per grid point; the decision needs every block's compare result (bit s =
+// "the next mask differs from mask s somewhere"): waves OR their bits into LDS, the block publishes its words with device-scope
+// stores into its own slots, a ticket counts retired blocks, and the last one ORs the slots.  Nothing contends on one address
+// except the ticket (one atomic per 1,024-thread block) -- the first version let every WAVE OR into one global word and spent
+// 40-60 us per sweep in those 3,000 same-address atomics, more than the three kernels it replaced.
+__global__ __launch_bounds__(kQmFinishThreads) void qm_finish_sweep(QmArgs a, int sweep)
 {
+    __shared__ unsigned int sh[kQmMaskWords + 1];
     if (a.flags[kQmDone]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < a.N;
+    const int nw = (sweep + 31) >> 5;
+    if (threadIdx.x <= kQmMaskWords) sh[threadIdx.x] = 0u;
+    __syncthreads();
     if (in) {
         const int b = a.bid[i];
         if (b >= 0) {                                                    // :2222-2231
@@ -189,24 +194,37 @@ __global__ __launch_bounds__(kQmThreads) void qm_finish_sweep(QmArgs a, int swee
         const bool ne = in && a.stack[(size_t)s * a.N + i] != m;
         if (__ballot(ne) != 0ull) word |= 1u << (s & 31);
         if ((s & 31) == 31 || s == sweep - 1) {
-            if ((threadIdx.x & 63) == 0 && word) atomicOr(reinterpret_cast<unsigned int *>(&a.diff[s >> 5]), word);
+            if ((threadIdx.x & 63) == 0 && word) atomicOr(&sh[s >> 5], word);
             word = 0u;
         }
     }
     if (in) a.stack[(size_t)sweep * a.N + i] = m;                        // :2272-2284 (harmless if we stop)
     __syncthreads();
+    // the block's words -> its own slots (device scope: the last block may sit on another XCD, behind another L2)
+    if ((int)threadIdx.x < nw)
+        __hip_atomic_store(reinterpret_cast<unsigned int *>(&a.diff[threadIdx.x * gridDim.x + blockIdx.x]), sh[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // acknowledged before the ticket below is taken
+    __syncthreads();
+    if (threadIdx.x == 0)
+        sh[kQmMaskWords] = __hip_atomic_fetch_add(&a.flags[kQmTicket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!sh[kQmMaskWords]) return;
+    // ---- the last block: OR of every block's words, then qm_decide
+    __syncthreads();
+    if (threadIdx.x < kQmMaskWords) sh[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nw * (int)gridDim.x; k += blockDim.x) {
+        const unsigned int v = __hip_atomic_load(reinterpret_cast<unsigned int *>(&a.diff[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) atomicOr(&sh[k / (int)gridDim.x], v);
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    __threadfence();
-    if (atomicAdd(&a.flags[kQmTicket], 1) != (int)gridDim.x - 1) return;
-    // ---- the last block: qm_decide
     a.flags[kQmTicket] = 0;
     bool fluct = false;
-    for (int w = 0; w <= (sweep - 1) >> 5; w++) {
-        const uint32_t have = __hip_atomic_load(reinterpret_cast<unsigned int *>(&a.diff[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = 0; w < nw; w++) {
         const int nbits = (sweep - 32 * w) < 32 ? (sweep - 32 * w) : 32;
         const uint32_t all = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
-        if ((have & all) != all) fluct = true;                           // some earlier mask equals the next one everywhere
-        a.diff[w] = 0;
+        if ((sh[w] & all) != all) fluct = true;                          // some earlier mask equals the next one everywhere
     }
     if (fluct) { a.flags[kQmSweeps] = sweep - 1; a.flags[kQmDone] = 1; return; }   // :2263-2268 (NOI--)
     a.flags[kQmSweeps] = sweep;
@@ -215,18 +233,21 @@ __global__ __launch_bounds__(kQmThreads) void qm_finish_sweep(QmArgs a, int swee
 }
 
 static inline int64_t pad256(int64_t n) { return (n + 255) & ~255LL; }
-static inline int64_t head_words(int32_t max_sweeps) { return (kQmFlagWords + (int64_t)max_sweeps + 2 + 63) & ~63LL; }
+static inline int64_t finish_blocks(int32_t n) { return ((int64_t)n + kQmFinishThreads - 1) / kQmFinishThreads; }
+// flag words + one slot per finish block and mask word (every sweep rewrites the slots it reads: no clearing)
+static inline int64_t head_words(int32_t n, int32_t max_sweeps) { return (kQmFlagWords + ((int64_t)max_sweeps + 32) / 32 * finish_blocks(n) + 63) & ~63LL; }
 
 int64_t qm_workspace_bytes(int32_t n, int32_t max_sweeps)
 {
     const int64_t N = pad256(n);
     // bx, by (f32) + bid (i32) + flags/diff words + mask[2][N] + stack[max_sweeps+1][N]
-    return 12 * N + 4 * head_words(max_sweeps) + 2 * N + N * (int64_t)(max_sweeps + 1);
+    return 12 * N + 4 * head_words(n, max_sweeps) + 2 * N + N * (int64_t)(max_sweeps + 1);
 }
 
 hipError_t launch_qm(QmArgs a, void *work, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
+    if (a.max_sweeps >= 32 * kQmMaskWords) return hipErrorInvalidValue;     // (the reference stops at 101 sweeps)
     const int64_t N = pad256(a.N);
     unsigned char *w = static_cast<unsigned char *>(work);
     a.bx = reinterpret_cast<float *>(w); w += 4 * N;
@@ -234,16 +255,17 @@ hipError_t launch_qm(QmArgs a, void *work, hipStream_t stream)
     a.bid = reinterpret_cast<int32_t *>(w); w += 4 * N;
     a.flags = reinterpret_cast<int32_t *>(w);
     a.diff = a.flags + kQmFlagWords;
-    w += 4 * head_words(a.max_sweeps);
+    w += 4 * head_words(a.N, a.max_sweeps);
     a.mask[0] = w; w += N;
     a.mask[1] = w; w += N;
     a.stack = w;
     const int nb = (int)((a.N + kQmThreads - 1) / kQmThreads);
+    const int nbf = (int)((a.N + kQmFinishThreads - 1) / kQmFinishThreads);
     const int nbi = (int)((((a.N > a.max_sweeps + 2) ? a.N : a.max_sweeps + 2) + kQmThreads - 1) / kQmThreads);
     hipLaunchKernelGGL(qm_init, dim3(nbi), dim3(kQmThreads), 0, stream, a);
     for (int s = 1; s <= a.max_sweeps; s++) {
         hipLaunchKernelGGL(qm_sweep, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
-        hipLaunchKernelGGL(qm_finish_sweep, dim3(nb), dim3(kQmThreads), 0, stream, a, s);
+        hipLaunchKernelGGL(qm_finish_sweep, dim3(nbf), dim3(kQmFinishThreads), 0, stream, a, s);
     }
     return hipGetLastError();
 }
