@@ -1,25 +1,34 @@
 // match_px_kernel.hip -- DLC/NCC matcher for gfx950, register-tiled kernel family.
 //
-// Same contract as match_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842).  One kernel
-// template, two pixel policies:
-//   PxU8   image pairs whose pixels are all integers in [0,255] (what GMA_float_load_tiff yields for
-//          an 8-bit TIFF, GMA.c:288-310).  Every running sum of the reference's NCC loop
-//          (MIMC_module.c:719-733: n, sx, sy, sxx, syy, sxy; f32 products, f64 accumulation) is then an
-//          exact integer < 2^31: v_dot4_u32_u8 on packed bytes, f64 only for the final formula (:734).
-//   PxF32  any f32 imagery (16-bit DN, filtered images, floats): f32 products, f64 accumulation in
-//          registers, exactly the reference's arithmetic up to the summation order.
+// Same contract as match_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842).  One kernel template,
+// match_ncc_dlc_px<PxCfg<Policy, OCW, LPC, NW, ...>>, and five pixel policies:
+//   PxU8    image pairs whose pixels are all integers in [0,255] (what GMA_float_load_tiff yields for an 8-bit TIFF,
+//           GMA.c:288-310).  Every running sum of the reference's NCC loop (MIMC_module.c:719-733: n, sx, sy, sxx, syy, sxy;
+//           f32 products, f64 accumulation) is an exact integer < 2^31: v_dot4_u32_u8 on packed bytes, f64 only for the
+//           final formula (:734).
+//   PxU16   scaled-integer pairs q = value * 2^s < 4096 (12-bit DN; the Laplacian of an 8-bit pair in 1/8 units):
+//           v_dot2_u32_u16, 64-bit cross-lane sums, exact power-of-two rescaling in the finish.
+//   PxU8o   integer u16 planes whose LOCAL range fits a byte (the gradients of an 8-bit pair), staged through a per-point
+//           offset onto the PxU8 machinery; the finish rebuilds the true integer sums.
+//   PxF32   any f32 imagery: f32 products, f64 accumulation in registers -- the reference's arithmetic up to summation order.
+//   PxF32i  PxF32 on planes whose pixels (x 1 or x 8) are integers below 2^20 (16-bit DN and its filtered forms): the sums
+//           are exact integers in any order, so they can come from tables (below).
 //
 // Layout / decomposition (one workgroup of NW wave64 = one grid point):
-//   * the images live in HBM as zero-bordered planes (border >= kU8Pad px, pitch a whole number of
-//     dwords), built once per image pair (prep_*_plane; the u8 one also PROVES the pair is 8-bit);
+//   * the images live in HBM as zero-bordered planes (border >= kU8Pad px, pitch a whole number of dwords), built once per
+//     image pair, each with a packed SUMMED-AREA TABLE (sat_kernel.hip): the sums of a null-free box of the window (sum b,
+//     sum b^2), the chip's sums and every null count are four-load box queries;
 //   * the DLC window is staged into LDS as aligned dwords (keeps the global pixel phase `sh`);
-//   * the chip lives in REGISTERS: each of the 64/LPC lane groups of a wave holds the whole chip,
-//     lane l of a group owns rows l, l+LPC, ... as dwords (+ a few single-dword "tail" tasks);
-//   * one evaluation round computes NW*64/LPC NCC cells: a lane slides over the aligned window dwords
-//     of its row (v_alignbyte_b32 when a dword holds several pixels), accumulates, and the LPC lanes
-//     of a cell are reduced with DPP row operations;
-//   * per-cell modes FAST / CHIPNULL / GENERAL (null handling), slot-mapped NCC cache, speculative
-//     parallel climb + exact replay of the reference's sequential hill climb (:691-753): see DESIGN.md.
+//   * the chip lives in REGISTERS: each of the 64/LPC lane groups of a wave holds the whole chip, lane l of a group owns rows
+//     l, l+LPC, ... as dwords (+ a few single-dword "tail" tasks);
+//   * one evaluation round computes NW*64/LPC NCC cells: a lane slides over the aligned window dwords of its row
+//     (v_alignbyte_b32 when a dword holds several pixels), accumulates, and the LPC lanes of a cell are reduced with DPP row
+//     operations (groups of 32 / 64 lanes: LDS atomics into the cell's parking slot);
+//   * per-cell modes: XY (null-free box and chip: only sxy is accumulated, the rest is constants + table), WN / GC / GENERAL
+//     (window nulls: three or six masked sums), CHIPNULL, sparse corrections over null lists on the big chips;
+//   * NCC cache: one f32 word per compact cell (or, COMPACT form for large windows, a 16-bit entry + value slots);
+//   * speculative parallel climb + exact replay of the reference's sequential hill climb (:691-753).
+// DESIGN.md section 4.1 describes each step and what was measured for it.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <atomic>
