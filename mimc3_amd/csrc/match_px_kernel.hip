@@ -147,7 +147,7 @@ struct PxU8 {
     static constexpr bool SAT = true;                         // the planes come with a packed summed-area table (sum b | sum b^2 | nulls)
     static constexpr bool SATZ = false;                       // ... whose null counts live in a second table (u16 planes)
     static constexpr bool SAT_CHIP = true;                    // the chip's sums and null count are table look-ups too
-    static constexpr bool WN = false;                         // three-sum body for window-null boxes: measured +1..2 % here (the masks are cheap next to the look-up)
+    static constexpr bool WN = true;                          // three-sum body for window-null boxes (per config: PxCfg::WN)
     typedef unsigned long long SatT;
     __device__ static __forceinline__ unsigned long long sat_s(SatT q) { return (uint32_t)q & ((1u << kSatSqShift8) - 1u); }
     __device__ static __forceinline__ unsigned long long sat_ss(SatT q) { return (uint32_t)(q >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u); }
@@ -552,6 +552,10 @@ struct PxCfg {
     // big chips: keep chip-derived masks out of registers (see PxU8::task).  Small chips: where the hoisted masks made the kernel
     // spill -- measured, same box, with / without: u8 ocw 16 3.10 / 3.22 ms, d/dx ocw 15 4.17 / 4.27; where it did not spill the
     // hoisted masks stay (u8 ocw 7 2.33 / 2.28, ocw 15 3.25 / 3.14 -- eight mask-deriving tail tasks --, Laplacian ocw 15 6.21 / 6.04)
+    // WN mode (window-null boxes of a null-free chip: three sums + table) per config, by measurement: every policy that allows it,
+    // but on 8-bit planes only where a lane owns two or more full chip rows and there are no null lists (u8 ocw 16: 3.14 -> 3.08 ms;
+    // ocw 7 / 15 / 40: +1.4 / +1.1 / +4 %, the byte masks being cheap next to the second table look-up)
+    static constexpr bool WN = P_::WN && (!std::is_same<P_, PxU8>::value || ((SHORT ? 1 : CW / LPC_) >= 2 && !((LPC_ >= 64) && P_::INTEGER)));
     static constexpr bool kOpqSmall = MIMC3_OPQ_SMALL && ((std::is_same<P_, PxU8>::value && OCW_ == 16) || (std::is_same<P_, PxU8o>::value && (OCW_ == 15 || OCW_ == 16)));
     static constexpr bool OPQ = LPC_ >= 64 || kOpqSmall;
     // Big chips with exact integer sums: a cell whose box (or whose chip) holds null pixels is evaluated as the FAST body
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         const bool dirty_list = (mode == M_GENERAL);
         // dirty boxes of a null-free chip, planes with a table: the WN body (three sums) instead of the six-sum GENERAL body --
         // except where a cell of the wave's round touches the never-written last row / column (T4: the table does not know it)
-        const bool wn_ok = kSat && (P::WN && kSat) && MIMC3_WN && dirty_list && exc_chip == 0;
+        const bool wn_ok = kSat && C::WN && MIMC3_WN && dirty_list && exc_chip == 0;
         // SPARSE: the lane's slice of the null lists lives in registers for the whole call (lists are per point)
         uint32_t ew[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, ec[2] = {0xffffffffu, 0xffffffffu};
         if constexpr (C::SPARSE) {
@@ -1899,7 +1903,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     MIMC3_STAMP(3)
     if (p.debug_stop == 6 || p.debug_stop == 7) { if (tid == 0) p.out[3 * (size_t)gidx] = best + (float)peak_u + (float)peak_v; return; }
     // ---- 3x3 quadratic fit (:757-788) ----------------------------------------------------------
-    if (tid == 0) {
+    // The reference's arithmetic, value by value (f32 linear combinations of the nine NCC values, widened, divided by 36 in
+    // f64; the two offsets as f32 expressions divided by the determinant in f64) -- but the five divisions by 36 run as ONE
+    // division on lanes 0..4 and the two by the determinant as one on lanes 0..1: an f64 division is ~30 instructions, and
+    // one lane doing seven of them in a row was 3 % of the kernel's vector instructions.
+    if (tid < 5) {
         float n9[9];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -1908,23 +1916,25 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 const int vb = (peak_v - 1 + r - OCW) * vpitch + (peak_u - 1 + c - OCW);
                 n9[3 * r + c] = ((vis[vb >> 5] >> (vb & 31)) & 1u) ? lookup(peak_u - 1 + c - OCW, peak_v - 1 + r - OCW) : -2.0f;   // visited = scanned = inside the band
             }
-        double cp0, cp1, cp2, cp3, cp4;
-        cp0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
-        cp1 = 9 * n9[0] - 9 * n9[2] - 9 * n9[6] + 9 * n9[8];
-        cp2 = 6 * n9[0] + 6 * n9[1] + 6 * n9[2] - 12 * n9[3] - 12 * n9[4] - 12 * n9[5] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
-        cp3 = -6 * n9[0] + 6 * n9[2] - 6 * n9[3] + 6 * n9[5] - 6 * n9[6] + 6 * n9[8];
-        cp4 = -6 * n9[0] - 6 * n9[1] - 6 * n9[2] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
-        cp0 /= 36; cp1 /= 36; cp2 /= 36; cp3 /= 36; cp4 /= 36;
-        float o0 = (float)(-2 * cp2 * cp3 + cp1 * cp4);
-        float o1 = (float)(-2 * cp0 * cp4 + cp1 * cp3);
+        const float e0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
+        const float e1 = 9 * n9[0] - 9 * n9[2] - 9 * n9[6] + 9 * n9[8];
+        const float e2 = 6 * n9[0] + 6 * n9[1] + 6 * n9[2] - 12 * n9[3] - 12 * n9[4] - 12 * n9[5] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+        const float e3 = -6 * n9[0] + 6 * n9[2] - 6 * n9[3] + 6 * n9[5] - 6 * n9[6] + 6 * n9[8];
+        const float e4 = -6 * n9[0] - 6 * n9[1] - 6 * n9[2] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+        double cp = (double)(tid == 0 ? e0 : (tid == 1 ? e1 : (tid == 2 ? e2 : (tid == 3 ? e3 : e4))));
+        cp /= 36;
+        auto from_lane = [&](int ln) __attribute__((always_inline)) -> double {
+            const long long bits = __double_as_longlong(cp);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, ln), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), ln);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        const double cp0 = from_lane(0), cp1 = from_lane(1), cp2 = from_lane(2), cp3 = from_lane(3), cp4 = from_lane(4);
+        const float num = tid == 0 ? (float)(-2 * cp2 * cp3 + cp1 * cp4) : (float)(-2 * cp0 * cp4 + cp1 * cp3);
         const double det = 4 * cp0 * cp2 - cp1 * cp1;
-        o0 = (float)((double)o0 / det);
-        o1 = (float)((double)o1 / det);
-        o0 += (float)(peak_u - pt.dx2);
-        o1 += (float)(peak_v - pt.dy2);
-        p.out[3 * (size_t)gidx + 0] = o0;
-        p.out[3 * (size_t)gidx + 1] = o1;
-        p.out[3 * (size_t)gidx + 2] = best;
+        float o = (float)((double)num / det);
+        o += (float)(tid == 0 ? peak_u - pt.dx2 : peak_v - pt.dy2);
+        if (tid < 2) p.out[3 * (size_t)gidx + tid] = o;
+        if (tid == 0) p.out[3 * (size_t)gidx + 2] = best;
     }
     MIMC3_STAMP(3)
 }
