@@ -230,6 +230,16 @@ typedef struct mimc3_cp_params {
 int mimc3_get_offset_image(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_cp_params *params,
                            int32_t offset[2], uint8_t *flag_cp, int32_t *status, int32_t *info /*[4]*/,
                            float *sduv /*[2]*/);
+/*      The same stage with its device work shared by `nctx` contexts (one per GPU, each holding the SAME pair):
+ *      the candidates of every segment are cut into nctx contiguous slices -- candidates are as independent as
+ *      grid points (MIMC_module.c:325-378) -- which the contexts match side by side on host threads of their
+ *      own.  What the reference does in sequence stays on the calling thread (the rand() shuffle, the segment
+ *      loop and its early exit, the chip-to-chip recurrence of the filtered planes' minima, the f32 vote sums in
+ *      candidate order): the result is that of the one-context call, whatever nctx is.  ctxs[0] does the
+ *      candidate selection and the segment-wide minima.  mimc3_mgpu_vmap calls this with all of its ranks.    */
+int mimc3_get_offset_image_multi(mimc3_ctx *const *ctxs, int32_t nctx, const double *xyuvav, int32_t N,
+                                 const mimc3_cp_params *params, int32_t offset[2], uint8_t *flag_cp,
+                                 int32_t *status, int32_t *info /*[4]*/, float *sduv /*[2]*/);
 
 /* ---- N3: the program's data path on arrays ---------------------------------------------------------------
  *      mimc3_postprocess replaces mimc2_postprocess (MIMC_module.h:48, MIMC_module.c:892-990): clustering ->

@@ -86,6 +86,8 @@ class CpParams(C.Structure):
                 ("seed", C.c_int64)]
 
 
+_lib.mimc3_get_offset_image_multi.argtypes = [C.POINTER(_vp), C.c_int32, _f64p, C.c_int32, C.POINTER(CpParams), _i32p,
+                                              np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(C.c_int32), _i32p, _f32p]
 _lib.mimc3_get_offset_image.argtypes = [_vp, _f64p, C.c_int32, C.POINTER(CpParams), _i32p,
                                         np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.POINTER(C.c_int32), _i32p, _f32p]
 
@@ -526,9 +528,11 @@ class Context:
 
     # -- N4: control-point offset -----------------------------------------------------------------
     def get_offset_image(self, xyuvav, kernels, seed=-1, vec_ocw=(7, 15, 30, 40), aw_cre=10.0, num_cp_max=500, num_cp_min=50,
-                         ratio_cp=0.03, thres_spd_cp=10.0):
+                         ratio_cp=0.03, thres_spd_cp=10.0, peers=()):
         """get_offset_image (MIMC_module.c:33-492) on the resident pair. Defaults = MIMC_main.c:134-170.
-        Returns (status, offset[2], flag_cp[N], info[4], sduv[2]); status 1 = ok, -1 = not enough control points."""
+        Returns (status, offset[2], flag_cp[N], info[4], sduv[2]); status 1 = ok, -1 = not enough control points.
+        peers: further Contexts holding the SAME pair (other GPUs) that share the device work (mimc3_get_offset_image_multi);
+        the result does not depend on them."""
         xy = np.ascontiguousarray(xyuvav, np.float64)
         ks = [np.ascontiguousarray(k, np.float32) for k in kernels]
         p = CpParams()
@@ -543,8 +547,13 @@ class Context:
         info = np.zeros(4, np.int32)
         sduv = np.zeros(2, np.float32)
         st = C.c_int32(0)
-        _check(_lib.mimc3_get_offset_image(self._h, xy, xy.shape[0], C.byref(p), off, flag, C.byref(st), info, sduv),
-               "get_offset_image")
+        if peers:
+            hs = (_vp * (1 + len(peers)))(self._h, *[q._h for q in peers])
+            _check(_lib.mimc3_get_offset_image_multi(hs, len(hs), xy, xy.shape[0], C.byref(p), off, flag, C.byref(st), info, sduv),
+                   "get_offset_image")
+        else:
+            _check(_lib.mimc3_get_offset_image(self._h, xy, xy.shape[0], C.byref(p), off, flag, C.byref(st), info, sduv),
+                   "get_offset_image")
         return st.value, off, flag, info, sduv
 
     # -- N2: image pre-filter ---------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/mimc3_hip.h"
 #include "host_util.h"
@@ -91,6 +92,7 @@ struct mimc3_ctx {
     const float *raw_i0 = nullptr, *raw_i1 = nullptr;   // the pair as handed over (before any pre-filter)
     DevBuf filt0, filt1, conv_io;       // pre-filtered pair (mimc3_ctx_filter_images), conv2 staging
     DevBuf cp_buf;                      // control-point stage: one arena carved per call
+    DevBuf cp_pre;                      // control-point stage: the filtered planes of a whole segment (their minima are settled before the slices start)
     bool filt_live = false;             // filt0/filt1 hold the output planes of an earlier filter pass on this pair
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // CP stage: its 16 small matcher launches per segment overlap on 4 streams
     hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1236,20 +1238,143 @@ struct CpClock {
 };
 }  // namespace
 
-extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_t N, const mimc3_cp_params *p, int32_t offset[2],
-                                      uint8_t *flag_cp, int32_t *status, int32_t *info, float *sduv_out)
+namespace {
+struct CpGeom { int ocw2, ocw_chip, cs, ts, awc, npiv; };
+
+// Device work of ONE SLICE of a segment of control-point candidates on context `c`: the chip atlases of the four image variants
+// for the slice's n candidates (tile t = candidate t; the filtered ones shifted by the minima `mn` the caller settled for the
+// WHOLE segment, T8), the 16 matches, the clusters.  mvn [n][16][5] / ncl [n] come back in host memory.  Candidates are as
+// independent as grid points (MIMC_module.c:325-378): a multi-GPU driver gives every rank a slice (mimc3_get_offset_image_multi).
+static int cp_slice(mimc3_ctx *c, const mimc3_cp_params *p, const CpGeom &g, const int32_t *uv, const float *const mn0[3], const float *const mn1[3],
+                    int32_t n, float *const pre_t0[3], float *const pre_t1[3], float *mvn, int32_t *ncl, CpClock *clk, int sg)
+{
+    if (n <= 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int H = c->H, W = c->W, cs = g.cs, ts = g.ts, ocw_chip = g.ocw_chip, npiv = g.npiv;
+    for (auto &st : c->side) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &ev : c->ev_side) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ch : c->cp_child) if (!ch) RC_TRY(ctx_create_impl(c->device, &ch, true));
+    const size_t nm = (size_t)n;
+    // four image variants (raw, three pre-filters) x an atlas pair each, three pairs of stencil scratch
+    const size_t need = al256(8 * nm) + al256(48 * nm) + al256(8 * npiv * nm) + al256(8 * (nm + 1)) + 8 * al256(4 * nm * cs * cs) +
+                        (pre_t0 ? 0 : 6) * al256(4 * nm * ts * ts) + 12 * al256(4 * nm) + al256(4 * 48 * nm) + al256(4 * 80 * nm) + al256(4 * nm) + 256;
+    HIP_TRY(c->cp_buf.reserve(need));
+    Arena ar(c->cp_buf.p, c->cp_buf.cap);
+    int32_t *d_uv = ar.take<int32_t>(2 * nm);
+    double *d_xy = ar.take<double>(6 * nm);
+    int32_t *d_piv = ar.take<int32_t>((size_t)2 * npiv * nm);
+    int64_t *d_poff = ar.take<int64_t>(nm + 1);
+    float *d_a0[4], *d_a1[4], *d_t0[3], *d_t1[3], *d_imin0[3], *d_imin1[3], *d_mn0[3], *d_mn1[3];
+    for (int v = 0; v < 4; v++) { d_a0[v] = ar.take<float>(nm * cs * cs); d_a1[v] = ar.take<float>(nm * cs * cs); }
+    for (int k = 0; k < 3; k++) {
+        // (the slice that starts at the segment's first candidate finds its filtered planes made: the minima pass left them)
+        d_t0[k] = pre_t0 ? pre_t0[k] : ar.take<float>(nm * ts * ts); d_t1[k] = pre_t1 ? pre_t1[k] : ar.take<float>(nm * ts * ts);
+        d_imin0[k] = ar.take<float>(nm); d_imin1[k] = ar.take<float>(nm); d_mn0[k] = ar.take<float>(nm); d_mn1[k] = ar.take<float>(nm);
+    }
+    float *d_dp = ar.take<float>(48 * nm);
+    float *d_mvn = ar.take<float>(80 * nm);
+    int32_t *d_ncl = ar.take<int32_t>(nm);
+    int32_t *d_kmax = ar.take<int32_t>(1);
+    // common rectangular pivot set (:150-162), replicated per point for the CSR interface (filled on the device)
+    HIP_TRY(mimc3::launch_cp_fill_problem(d_xy, d_piv, d_poff, n, g.awc, ocw_chip, cs, s));
+    HIP_TRY(hipMemcpyAsync(d_uv, uv, 8 * nm, hipMemcpyHostToDevice, s));
+    // ---- the chip atlases of the four image variants: raw chips, then the three pre-filters shifted by the settled minima
+    HIP_TRY(mimc3::launch_cp_extract(c->raw_i0, H, W, d_uv, n, ocw_chip, d_a0[0], s));
+    HIP_TRY(mimc3::launch_cp_extract(c->raw_i1, H, W, d_uv, n, ocw_chip, d_a1[0], s));
+    for (int kk = 0; kk < 3; kk++) {
+        const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
+        if (!pre_t0) {
+            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t0[kk], d_imin0[kk], s));
+            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t1[kk], d_imin1[kk], s));
+        }
+        HIP_TRY(hipMemcpyAsync(d_mn0[kk], mn0[kk], 4 * nm, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_mn1[kk], mn1[kk], 4 * nm, hipMemcpyHostToDevice, s));
+        HIP_TRY(mimc3::launch_cp_shift_copy(d_t0[kk], d_mn0[kk], n, ocw_chip, d_a0[kk + 1], s));
+        HIP_TRY(mimc3::launch_cp_shift_copy(d_t1[kk], d_mn1[kk], n, ocw_chip, d_a1[kk + 1], s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));                                          // the atlases are complete
+    if (clk) clk->mark("atlases", sg);
+    // ---- every atlas is an image pair of its own, handed to a child context that classifies it (8-bit / scaled integers /
+    //      floats) and runs the same tiled kernels as the DLC passes: full-square search area (win_half), the 21x21 pivot
+    //      set as a replicated CSR
+    //      The 16 matches (:330-384): one match is a few hundred workgroups, latency-bound on its own -- the four of a
+    //      variant (2 chip sizes x forward/swapped) go to four streams, each with its own overflow lists, and the variants
+    //      follow each other on those streams without a host round trip; variant v+1 is classified while v's matches run
+    auto matches = [&]() -> int {
+        for (int v = 0; v < 4; v++) {
+            mimc3_ctx *ch = c->cp_child[v];
+            ch->path_mode = c->path_mode;
+            // gradients go straight to the u16 kernel: over a whole 85x85 search area their range rarely fits the 8 bits
+            // of the per-point-offset form, and a second launch for the points that do not costs a full kernel latency
+            ch->no_u8o = true;
+            RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
+            ch->win_half = ocw_chip;
+            if (!ch->u8_ok && !ch->u16_ok) {       // float / 16-bit atlas: the f32 planes are built lazily by the first match
+                RC_TRY(build_f32_planes(ch, ch->stream));   // -- here the four matches start on four streams, so build them first
+                HIP_TRY(hipStreamSynchronize(ch->stream));
+            }
+            for (int c3 = 1; c3 < 3; c3++) {
+                const int ocw = p->vec_ocw[c3];
+                const int32_t slot = (c3 - 1) * 8 + v * 2;
+                const int reach = ocw_chip - ocw - 2;
+                for (int sw = 0; sw < 2; sw++) {
+                    const int lane_id = (c3 - 1) * 2 + sw;                     // 0..3
+                    hipStream_t ms = lane_id == 0 ? s : c->side[lane_id - 1];
+                    float *o = d_dp + (size_t)(slot + sw) * n * 3;
+                    ch->lane = lane_id;
+                    int rc = mimc3_match_ncc_dlc_dev(ch, d_xy, n, 0, 0, d_piv, d_poff, npiv, reach, reach, ocw, sw, o, ms);
+                    ch->lane = 0;
+                    if (rc) return rc;
+                    if (sw) HIP_TRY(mimc3::launch_negate_uv(o, n, ms));         // :376-377
+                }
+            }
+        }
+        return 0;
+    };
+    const int mrc = matches();
+    for (auto &ch : c->cp_child) ch->win_half = 0;
+    for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (mrc) return mrc;
+    if (clk) clk->mark("classify + matches", sg);
+    // ---- clusters of the 16 matches (:392-413)
+    mimc3::ClusterArgs ca{};
+    ca.dp = d_dp; ca.ndp = 16; ca.N = n; ca.Kmax = 16; ca.mvn = d_mvn; ca.nclus = d_ncl; ca.kmax_seen = d_kmax;
+    HIP_TRY(mimc3::launch_cluster(ca, s));
+    HIP_TRY(hipMemcpyAsync(mvn, d_mvn, 4 * 80 * nm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ncl, d_ncl, 4 * nm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+}  // namespace
+
+// The control-point offset on one context, or -- nctx > 1 -- with the candidates of every segment cut into slices that the
+// contexts (one per device, all holding the same image pair) match side by side, each on a host thread of its own.  Everything
+// that is sequential in the reference stays on the calling thread: the rand() shuffle, the segment loop with its early exit, the
+// chip-to-chip recurrence of the filtered planes' minima (T8), the f32 vote sums in candidate order -- the result does not depend
+// on how many contexts share the work.
+extern "C" int mimc3_get_offset_image_multi(mimc3_ctx *const *ctxs, int32_t nctx, const double *xyuvav, int32_t N, const mimc3_cp_params *p,
+                                            int32_t offset[2], uint8_t *flag_cp, int32_t *status, int32_t *info, float *sduv_out)
 {
     CpClock clk;
-    if (!c || !xyuvav || !p || !offset || !flag_cp || !status || N <= 0)
+    if (!ctxs || nctx < 1 || nctx > 64 || !xyuvav || !p || !offset || !flag_cp || !status || N <= 0)
         return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: bad argument");
-    if (!c->raw_i0 || !c->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: images not set");
+    mimc3_ctx *c = ctxs[0];
+    for (int32_t r = 0; r < nctx; r++) {
+        if (!ctxs[r]) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: a context is NULL");
+        if (!ctxs[r]->raw_i0 || !ctxs[r]->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: images not set");
+        if (ctxs[r]->H != c->H || ctxs[r]->W != c->W) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: the contexts hold different image pairs");
+    }
     for (int k = 0; k < 3; k++)
         if (!p->kernel[k] || p->kdim[k][0] < 1 || p->kdim[k][0] > 3 || p->kdim[k][1] < 1 || p->kdim[k][1] > 3)
             return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: three pre-filter kernels of at most 3x3 are required");
-    const int ocw2 = p->vec_ocw[2];
-    const int ocw_chip = (int32_t)(p->vec_ocw[2] + p->aw_cre + 2);                 // :51
-    const int cs = 2 * ocw_chip + 1, ts = cs + 2;
-    const int awc = (int)p->aw_cre;
+    CpGeom g{};
+    g.ocw2 = p->vec_ocw[2];
+    g.ocw_chip = (int32_t)(p->vec_ocw[2] + p->aw_cre + 2);                        // :51
+    g.cs = 2 * g.ocw_chip + 1; g.ts = g.cs + 2;
+    g.awc = (int)p->aw_cre;
+    const int ocw2 = g.ocw2, ocw_chip = g.ocw_chip, awc = g.awc;
     if (ocw2 < 1 || p->vec_ocw[1] < 1 || p->vec_ocw[1] > ocw2 || awc < 0 || ocw_chip - ocw2 - 2 < 0)
         return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: need 1 <= vec_ocw[1] <= vec_ocw[2] and AW_CRE >= 0");
     *status = -1;
@@ -1258,16 +1383,14 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int H = c->H, W = c->W;
-    for (auto &st : c->side) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    for (auto &ev : c->ev_side) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     // ---- candidates: slow a-priori points (:64-78) whose ocw[2] chip of i0 is mostly valid (:81-112)
     int32_t num_cp;
     if (N * p->ratio_cp > p->num_cp_max) num_cp = p->num_cp_max; else num_cp = (int32_t)(N * p->ratio_cp);
     std::vector<int32_t> rows;
-    for (int32_t g = 0; g < N; g++) {
-        const float spd = xyuvav[6 * (size_t)g + 4] * xyuvav[6 * (size_t)g + 4] + xyuvav[6 * (size_t)g + 5] * xyuvav[6 * (size_t)g + 5];
-        if (spd < p->thres_spd_cp * p->thres_spd_cp) rows.push_back(g);
+    for (int32_t gi = 0; gi < N; gi++) {
+        const float spd = xyuvav[6 * (size_t)gi + 4] * xyuvav[6 * (size_t)gi + 4] + xyuvav[6 * (size_t)gi + 5] * xyuvav[6 * (size_t)gi + 5];
+        if (spd < p->thres_spd_cp * p->thres_spd_cp) rows.push_back(gi);
     }
     std::vector<int32_t> uv(2 * rows.size());
     for (size_t i = 0; i < rows.size(); i++) {
@@ -1317,34 +1440,11 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         seg[k] = (int32_t)(ncand * ((float)k / (float)nseg));                      // :179
         nmax = std::max(nmax, seg[k] - seg[k - 1]);
     }
+    g.npiv = (int32_t)((p->aw_cre * 2 + 1) * (p->aw_cre * 2 + 1));
+    if (g.npiv != (2 * awc + 1) * (2 * awc + 1)) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: AW_CRE must be integral");
 
-    // ---- common rectangular pivot set (:150-162), replicated per point for the CSR interface (filled on the device)
-    const int32_t npiv = (int32_t)((p->aw_cre * 2 + 1) * (p->aw_cre * 2 + 1));
-    if (npiv != (2 * awc + 1) * (2 * awc + 1)) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: AW_CRE must be integral");
-
-    const size_t nm = (size_t)nmax;
-    // four image variants (raw, three pre-filters) x an atlas pair each, three pairs of stencil scratch
-    const size_t need = al256(8 * nm) + al256(48 * nm) + al256(8 * npiv * nm) + al256(8 * (nm + 1)) + 8 * al256(4 * nm * cs * cs) +
-                        6 * al256(4 * nm * ts * ts) + 12 * al256(4 * nm) + al256(4 * 48 * nm) + al256(4 * 80 * nm) + al256(4 * nm) + 256;
-    HIP_TRY(c->cp_buf.reserve(need));
-    Arena ar(c->cp_buf.p, c->cp_buf.cap);
-    int32_t *d_uv = ar.take<int32_t>(2 * nm);
-    double *d_xy = ar.take<double>(6 * nm);
-    int32_t *d_piv = ar.take<int32_t>((size_t)2 * npiv * nm);
-    int64_t *d_poff = ar.take<int64_t>(nm + 1);
-    float *d_a0[4], *d_a1[4], *d_t0[3], *d_t1[3], *d_imin0[3], *d_imin1[3], *d_mn0[3], *d_mn1[3];
-    for (int v = 0; v < 4; v++) { d_a0[v] = ar.take<float>(nm * cs * cs); d_a1[v] = ar.take<float>(nm * cs * cs); }
-    for (int k = 0; k < 3; k++) {
-        d_t0[k] = ar.take<float>(nm * ts * ts); d_t1[k] = ar.take<float>(nm * ts * ts);
-        d_imin0[k] = ar.take<float>(nm); d_imin1[k] = ar.take<float>(nm); d_mn0[k] = ar.take<float>(nm); d_mn1[k] = ar.take<float>(nm);
-    }
-    float *d_dp = ar.take<float>(48 * nm);
-    float *d_mvn = ar.take<float>(80 * nm);
-    int32_t *d_ncl = ar.take<int32_t>(nm);
-    int32_t *d_kmax = ar.take<int32_t>(1);
-    HIP_TRY(mimc3::launch_cp_fill_problem(d_xy, d_piv, d_poff, nmax, awc, ocw_chip, cs, s));
-    for (auto &ch : c->cp_child) if (!ch) RC_TRY(ctx_create_impl(c->device, &ch, true));
-
+    // per-chip minima of the filtered chips of a whole segment (context 0): scratch for the stencil planes + the minima
+    const size_t nm = (size_t)nmax, ts = (size_t)g.ts;
     clk.mark("setup + uploads");
     float sduv[2] = {0.0f, 0.0f};
     int32_t ncur = 0, segs = 0;
@@ -1359,19 +1459,24 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
         if (n <= 0) continue;
         uv_seg.resize(2 * (size_t)n);
         for (int32_t t = 0; t < n; t++) { uv_seg[2 * t] = uv[2 * order[beg + t]]; uv_seg[2 * t + 1] = uv[2 * order[beg + t] + 1]; }
-        HIP_TRY(hipMemcpyAsync(d_uv, uv_seg.data(), 8 * (size_t)n, hipMemcpyHostToDevice, s));
-        // ---- the chip atlases of the four image variants (tile t = candidate t): raw chips, then the three pre-filters.
-        //      The filters' minima go through the host once (the reference's plane-reuse rule below is a serial scan).
-        HIP_TRY(mimc3::launch_cp_extract(c->raw_i0, H, W, d_uv, n, ocw_chip, d_a0[0], s));
-        HIP_TRY(mimc3::launch_cp_extract(c->raw_i1, H, W, d_uv, n, ocw_chip, d_a1[0], s));
-        for (int kk = 0; kk < 3; kk++) {
-            const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
-            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t0[kk], d_imin0[kk], s));
-            HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, d_t1[kk], d_imin1[kk], s));
-            HIP_TRY(hipMemcpyAsync(imin0[kk].data(), d_imin0[kk], 4 * (size_t)n, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(imin1[kk].data(), d_imin1[kk], 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+        float *pre_t0[3], *pre_t1[3];
+        {   // the filters' per-chip minima of the WHOLE segment, then the reference's plane-reuse rule: a serial scan on the host
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(c->cp_pre.reserve(al256(8 * nm) + 6 * al256(4 * nm * ts * ts) + 6 * al256(4 * nm) + 256));
+            Arena ar(c->cp_pre.p, c->cp_pre.cap);
+            int32_t *d_uv = ar.take<int32_t>(2 * nm);
+            HIP_TRY(hipMemcpyAsync(d_uv, uv_seg.data(), 8 * (size_t)n, hipMemcpyHostToDevice, s));
+            for (int kk = 0; kk < 3; kk++) {
+                const int kh = p->kdim[kk][0], kw = p->kdim[kk][1];
+                pre_t0[kk] = ar.take<float>(nm * ts * ts); pre_t1[kk] = ar.take<float>(nm * ts * ts);
+                float *d_m0 = ar.take<float>(nm), *d_m1 = ar.take<float>(nm);
+                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i0, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, pre_t0[kk], d_m0, s));
+                HIP_TRY(mimc3::launch_cp_conv_min(c->raw_i1, H, W, d_uv, n, ocw_chip, p->kernel[kk], kh, kw, pre_t1[kk], d_m1, s));
+                HIP_TRY(hipMemcpyAsync(imin0[kk].data(), d_m0, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(imin1[kk].data(), d_m1, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+            }
+            HIP_TRY(hipStreamSynchronize(s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
         for (int kk = 0; kk < 3; kk++) {
             // the reference's output plane is reused from point to point (:259-262): its never-written border cells
             // stay 0 (T4), its right-hand border columns accumulate the shifts (:2568-2582); both enter the minimum
@@ -1391,63 +1496,30 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
                     if (ox > 0) b = (b != b) ? 0.0f : b - (m - 1.0f);
                 }
             }
-            HIP_TRY(hipMemcpyAsync(d_mn0[kk], mn0[kk].data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_mn1[kk], mn1[kk].data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
-            HIP_TRY(mimc3::launch_cp_shift_copy(d_t0[kk], d_mn0[kk], n, ocw_chip, d_a0[kk + 1], s));
-            HIP_TRY(mimc3::launch_cp_shift_copy(d_t1[kk], d_mn1[kk], n, ocw_chip, d_a1[kk + 1], s));
         }
-        HIP_TRY(hipStreamSynchronize(s));                                          // the atlases are complete
-        clk.mark("atlases", sg);
-        // ---- every atlas is an image pair of its own, handed to a child context that classifies it (8-bit / scaled integers /
-        //      floats) and runs the same tiled kernels as the DLC passes: full-square search area (win_half), the 21x21 pivot
-        //      set as a replicated CSR
-        //      The 16 matches (:330-384): one match is a few hundred workgroups, latency-bound on its own -- the four of a
-        //      variant (2 chip sizes x forward/swapped) go to four streams, each with its own overflow lists, and the variants
-        //      follow each other on those streams without a host round trip; variant v+1 is classified while v's matches run
-        auto matches = [&]() -> int {
-            for (int v = 0; v < 4; v++) {
-                mimc3_ctx *ch = c->cp_child[v];
-                ch->path_mode = c->path_mode;
-                // gradients go straight to the u16 kernel: over a whole 85x85 search area their range rarely fits the 8 bits
-                // of the per-point-offset form, and a second launch for the points that do not costs a full kernel latency
-                ch->no_u8o = true;
-                RC_TRY(set_images_dev_impl(ch, d_a0[v], d_a1[v], n * cs, cs, false));
-                ch->win_half = ocw_chip;
-                if (!ch->u8_ok && !ch->u16_ok) {       // float / 16-bit atlas: the f32 planes are built lazily by the first match
-                    RC_TRY(build_f32_planes(ch, ch->stream));   // -- here the four matches start on four streams, so build them first
-                    HIP_TRY(hipStreamSynchronize(ch->stream));
-                }
-                for (int c3 = 1; c3 < 3; c3++) {
-                    const int ocw = p->vec_ocw[c3];
-                    const int32_t slot = (c3 - 1) * 8 + v * 2;
-                    const int reach = ocw_chip - ocw - 2;
-                    for (int sw = 0; sw < 2; sw++) {
-                        const int lane_id = (c3 - 1) * 2 + sw;                     // 0..3
-                        hipStream_t ms = lane_id == 0 ? s : c->side[lane_id - 1];
-                        float *o = d_dp + (size_t)(slot + sw) * n * 3;
-                        ch->lane = lane_id;
-                        int rc = mimc3_match_ncc_dlc_dev(ch, d_xy, n, 0, 0, d_piv, d_poff, npiv, reach, reach, ocw, sw, o, ms);
-                        ch->lane = 0;
-                        if (rc) return rc;
-                        if (sw) HIP_TRY(mimc3::launch_negate_uv(o, n, ms));         // :376-377
-                    }
-                }
-            }
-            return 0;
-        };
-        const int mrc = matches();
-        for (auto &ch : c->cp_child) ch->win_half = 0;
-        for (auto &st : c->side) HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (mrc) return mrc;
-        clk.mark("classify + matches", sg);
-        // ---- clusters of the 16 matches; those holding >= 60 % vote with their mean (:392-413)
-        mimc3::ClusterArgs ca{};
-        ca.dp = d_dp; ca.ndp = 16; ca.N = n; ca.Kmax = 16; ca.mvn = d_mvn; ca.nclus = d_ncl; ca.kmax_seen = d_kmax;
-        HIP_TRY(mimc3::launch_cluster(ca, s));
-        HIP_TRY(hipMemcpyAsync(mvn.data(), d_mvn, 4 * 80 * (size_t)n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ncl.data(), d_ncl, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        clk.mark("minima", sg);
+        // ---- the slices: contexts 1.. on host threads of their own, context 0 here
+        {
+            const int32_t R = nctx < n ? nctx : n;
+            std::vector<int> rcs((size_t)R, 0);
+            std::vector<std::string> errs((size_t)R);
+            auto run = [&](int32_t r) {
+                const int32_t t0 = (int32_t)((int64_t)n * r / R), t1 = (int32_t)((int64_t)n * (r + 1) / R);
+                const float *a0[3] = {mn0[0].data() + t0, mn0[1].data() + t0, mn0[2].data() + t0};
+                const float *a1[3] = {mn1[0].data() + t0, mn1[1].data() + t0, mn1[2].data() + t0};
+                rcs[(size_t)r] = cp_slice(ctxs[r], p, g, uv_seg.data() + 2 * (size_t)t0, a0, a1, t1 - t0, r == 0 ? pre_t0 : nullptr, r == 0 ? pre_t1 : nullptr, mvn.data() + 80 * (size_t)t0, ncl.data() + t0,
+                                          r == 0 ? &clk : nullptr, sg);
+                if (rcs[(size_t)r]) errs[(size_t)r] = mimc3_last_error();        // (the message is thread-local)
+            };
+            std::vector<std::thread> th;
+            for (int32_t r = 1; r < R; r++) th.emplace_back(run, r);
+            run(0);
+            for (auto &t : th) t.join();
+            for (int32_t r = 0; r < R; r++)
+                if (rcs[(size_t)r]) return mimc3::fail(rcs[(size_t)r], errs[(size_t)r]);
+            HIP_TRY(hipSetDevice(c->device));
+        }
+        // ---- clusters holding >= 60 % vote with their mean, in candidate order (:392-413)
         for (int32_t t = 0; t < n; t++)
             for (int32_t k = 0; k < ncl[t]; k++)
                 if (mvn[((size_t)t * 16 + k) * 5 + 4] >= 0.6) {
@@ -1468,6 +1540,14 @@ extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_
     offset[1] = dv > 0 ? (int32_t)(dv + 0.5) : (int32_t)(dv - 0.5);
     *status = 1;
     return 0;
+}
+
+extern "C" int mimc3_get_offset_image(mimc3_ctx *c, const double *xyuvav, int32_t N, const mimc3_cp_params *p, int32_t offset[2],
+                                      uint8_t *flag_cp, int32_t *status, int32_t *info, float *sduv_out)
+{
+    if (!c) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: bad argument");
+    mimc3_ctx *one[1] = {c};
+    return mimc3_get_offset_image_multi(one, 1, xyuvav, N, p, offset, flag_cp, status, info, sduv_out);
 }
 
 // ---------------------------------------------------------------------------------------------

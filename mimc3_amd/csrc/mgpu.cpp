@@ -346,7 +346,7 @@ extern "C" int mimc3_mgpu_vmap(mimc3_mgpu *mg, const double *xyuvav, int32_t N, 
     RC_TRY(mimc3::vmap_geometry(xyuvav, N, res));
     const float mpp = res->mpp;
 
-    // while device 0 measures the CP offset (once, for every rank), a host thread counts the pivots of the four chip sizes
+    // while the devices measure the CP offset (once; every segment of candidates cut into one slice per rank), a host thread counts the pivots of the four chip sizes
     // for the whole grid (the cheap half of get_uv_pivot) and cuts the grid into cost-balanced shares
     std::vector<int32_t> order((size_t)N), start((size_t)world + 1);
     int part_rc = 0;
@@ -365,7 +365,7 @@ extern "C" int mimc3_mgpu_vmap(mimc3_mgpu *mg, const double *xyuvav, int32_t N, 
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{part_worker};
     HIP_TRY(hipSetDevice(mg->dev[0]));
-    RC_TRY(mimc3::vmap_cp_offset(mg->ctx[0], xyuvav, N, p, flag_cp, res));
+    RC_TRY(mimc3::vmap_cp_offset(mg->ctx.data(), world, xyuvav, N, p, flag_cp, res));
     part_worker.join();
     if (res->cp_status < 0) return 0;                        // the CLI touches vmap.tar and gives up (:248-252)
     if (part_rc) return mimc3::fail(part_rc, part_err);

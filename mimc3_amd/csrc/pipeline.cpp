@@ -200,8 +200,9 @@ int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, flo
 }
 
 // CP offset on the whole grid (:240-256): fills res->cp_status / offset_cp and flag_cp
-int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res)
+int vmap_cp_offset(mimc3_ctx *const *ctxs, int32_t nctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res)
 {
+    mimc3_ctx *ctx = ctxs[0];
     mimc3_cp_params cp{};
     for (int k = 0; k < 4; k++) cp.vec_ocw[k] = p->vec_ocw[k];
     cp.aw_cre = p->aw_cre; cp.num_cp_max = p->num_cp_max; cp.num_cp_min = p->num_cp_min;
@@ -210,7 +211,7 @@ int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_
     std::memset(flag_cp, 0, (size_t)N);
     int32_t off[2] = {0, 0}, st = -1;
     RC_TRY(mimc3_ctx_filter_images(ctx, nullptr, 0, 0));
-    RC_TRY(mimc3_get_offset_image(ctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
+    RC_TRY(mimc3_get_offset_image_multi(ctxs, nctx, xyuvav, N, &cp, off, flag_cp, &st, nullptr, nullptr));
     res->cp_status = st;
     if (st >= 0) { res->offset_cp[0] = off[0]; res->offset_cp[1] = off[1]; }
     return 0;
@@ -298,7 +299,7 @@ extern "C" int mimc3_vmap_passes(mimc3_ctx *ctx, const double *xyuvav, int32_t N
     const float mpp = res->mpp;
     std::thread piv_worker([&]() { piv_rc = mimc3::vmap_host_pivots(ctx, xs, ns, dt, mpp, p, H, W, hp, piv_err); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{piv_worker};
-    RC_TRY(mimc3::vmap_cp_offset(ctx, xyuvav, N, p, flag_cp, res));
+    RC_TRY(mimc3::vmap_cp_offset(&ctx, 1, xyuvav, N, p, flag_cp, res));
     if (res->cp_status < 0) return 0;                       // the CLI touches vmap.tar and gives up (:248-252)
     clk.mark("control-point offset", s);
     piv_worker.join();
@@ -323,7 +324,7 @@ extern "C" int mimc3_vmap_cp(mimc3_ctx *ctx, const double *xyuvav, int32_t N, fl
     if (!ctx || !xyuvav || !p || !flag_cp || !res || N < 2) return mimc3::fail(MIMC3_EINVAL, "mimc3_vmap_cp: bad argument");
     std::memset(res, 0, sizeof(*res));
     RC_TRY(mimc3::vmap_geometry(xyuvav, N, res));
-    return mimc3::vmap_cp_offset(ctx, xyuvav, N, p, flag_cp, res);
+    return mimc3::vmap_cp_offset(&ctx, 1, xyuvav, N, p, flag_cp, res);
 }
 
 extern "C" int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_t n, float dt, const mimc3_vmap_params *p,

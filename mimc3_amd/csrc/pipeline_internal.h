@@ -25,7 +25,8 @@ struct HostPivots {
 int vmap_geometry(const double *xyuvav, int32_t N, mimc3_vmap_result *res);
 int vmap_host_pivots(mimc3_ctx *ctx, const double *xs, int32_t ns, float dt, float mpp, const mimc3_vmap_params *p, int32_t H, int32_t W,
                      HostPivots hp[4], std::string &err);
-int vmap_cp_offset(mimc3_ctx *ctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res);
+// (nctx > 1: the candidates of a segment are matched in slices, one per context -- mimc3_get_offset_image_multi)
+int vmap_cp_offset(mimc3_ctx *const *ctxs, int32_t nctx, const double *xyuvav, int32_t N, const mimc3_vmap_params *p, uint8_t *flag_cp, mimc3_vmap_result *res);
 int vmap_run_passes(mimc3_ctx *ctx, const double *xs, int32_t ns, const int32_t off[2], HostPivots hp[4], const mimc3_vmap_params *p,
                     float *d_dp, size_t pass_stride);
 

@@ -56,6 +56,31 @@ def test_vs_oracle(api, oracle, name, seed):
         assert st == 1 and tuple(off) == CASES[name]["shift"]
 
 
+@pytest.mark.parametrize("name,peers", [("clean", 1), ("torn_heavy_nulls", 2), ("torn_noise", 3), ("nulls_noise", 7)])
+def test_slices_over_several_contexts(api, oracle, name, peers):
+    """mimc3_get_offset_image_multi: every segment's candidates cut into slices matched by 1 + peers contexts on host threads
+    of their own (here all on the one device): status, offset, flags, counts and the f32 vote sums of the oracle, as with one."""
+    i0, i1, xy = cp_case(**CASES[name])
+    rc, off, flag, info, sduv = oracle.get_offset_image(i0, i1, xy, K, 5, num_cp_min=20)
+    ctxs = [api.Context(0) for _ in range(1 + peers)]
+    try:
+        for c in ctxs:
+            c.set_images(i0, i1)
+        st, o2, f2, info2, sduv2 = ctxs[0].get_offset_image(xy, K, seed=5, num_cp_min=20, peers=ctxs[1:])
+        # a peer that holds another pair is refused, not used
+        ctxs[-1].set_images(i0[:-8], i1[:-8])
+        with pytest.raises(api.Mimc3Error):
+            ctxs[0].get_offset_image(xy, K, seed=5, num_cp_min=20, peers=ctxs[1:])
+    finally:
+        for c in ctxs:
+            c.close()
+    assert st == rc
+    assert np.array_equal(info2, info), (info2, info)
+    assert np.array_equal(f2, flag)
+    assert np.array_equal(sduv2.view(np.uint32), sduv.view(np.uint32)), (sduv2, sduv)
+    assert np.array_equal(o2, off)
+
+
 @pytest.mark.parametrize("seed", [3, 99])
 def test_16bit_pair_vs_oracle(api, oracle, seed):
     """16-bit DN: the atlases of all four image variants take the register-tiled f32 kernel (16 concurrent matches on four

@@ -17,8 +17,13 @@ xy = c.xyuvav.copy()
 rng = np.random.default_rng(1)
 slow = rng.random(xy.shape[0]) < 0.05
 xy[slow, 4] = rng.uniform(-5, 5, slow.sum()); xy[slow, 5] = rng.uniform(-5, 5, slow.sum())
+npeer = int(os.environ.get("CP_PEERS", "0"))          # further contexts on the same device sharing every segment (the multi-GPU form)
+peers = [api.Context(0) for _ in range(npeer)]
 with api.Context(0) as ctx:
-    ctx.set_images(c.i0, c.i1)
+    for q in [ctx] + peers:
+        q.set_images(c.i0, c.i1)
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-        t = time.time(); st, off, flag, info, sduv = ctx.get_offset_image(xy, api.CLI_KERNELS, seed=7); dt = time.time() - t
-        print(json.dumps({"cp_s": dt, "status": st, "offset": off.tolist(), "info": info.tolist(), "sduv": sduv.tolist()}), flush=True)
+        t = time.time(); st, off, flag, info, sduv = ctx.get_offset_image(xy, api.CLI_KERNELS, seed=7, peers=peers); dt = time.time() - t
+        print(json.dumps({"cp_s": dt, "peers": npeer, "status": st, "offset": off.tolist(), "info": info.tolist(), "sduv": sduv.tolist()}), flush=True)
+for q in peers:
+    q.close()
