@@ -54,6 +54,9 @@
 #ifndef MIMC3_OPQ_SMALL
 #define MIMC3_OPQ_SMALL 1       // keep the chip-derived masks of the small chips out of registers too (only chips with nulls derive any: GC mode)
 #endif
+#ifndef MIMC3_FAST_REPLAY
+#define MIMC3_FAST_REPLAY 1     // exact replay on scan centres the lanes decoded beforehand (register visited set, <= 64 pivots)
+#endif
 #ifndef MIMC3_GC
 #define MIMC3_GC 1              // six-sum body with compile-time chip masks for null-free chips
 #endif
@@ -1743,6 +1746,52 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             unsigned long long ntr = 0ull;           // many-pivot configurations: the record of pivot kk + 1 (>= 64), read one pivot ahead
             int nqu = 0, nqv = 0, ninfo = 0;
             bool xcut = false;
+            // Register visited set, one lane per pivot: every lane first decodes ITS trajectory into scan centres (8 + 8 bits per
+            // scan, two per register) and a "this scan moved" mask -- in parallel, where the sequential loop used to decode the
+            // 4-bit codes scan by scan on the scalar unit; what stays sequential is one lane read, the 3 x 3-bit test-and-set on
+            // the three row lanes and the continue test per scan (the chain was 19 k of a point's 126 k cycles at BASELINE C2).
+            constexpr bool kFastReplay = MIMC3_FAST_REPLAY && !C::MANYP;
+            constexpr int kFastScans = 8;                 // scans per pivot the decoded form holds (4 registers); longer speculations: the loop below
+            if (kFastReplay && regmask && __ballot(nsc > kFastScans) == 0ull) {
+                uint32_t pos[kFastScans / 2] = {0u, 0u, 0u, 0u};
+                uint32_t mvmask = 0u;
+                {
+                    int x = start_u - OCW, y = start_v - OCW;
+#pragma unroll
+                    for (int t = 0; t < kFastScans; t++) {
+                        if (__ballot(nsc > t) == 0ull) break;
+                        const uint32_t code = (uint32_t)(traj >> (4 * t)) & 15u;
+                        pos[t >> 1] |= ((uint32_t)x | ((uint32_t)y << 8)) << (16 * (t & 1));
+                        const bool moved = (code - 1u) < 9u && code != 5u;
+                        const int mv = (int)code - 1, q3 = (mv * 11) >> 5;
+                        x += moved ? q3 - 1 : 0; y += moved ? (mv - 3 * q3) - 1 : 0;
+                        mvmask |= moved ? (1u << t) : 0u;
+                    }
+                }
+                const int lane1 = lane + 1;
+                for (int kk = 0; kk < npiv; kk++) {
+                    const int n_k = __builtin_amdgcn_readlane(nsc, kk);
+                    uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mvmask, kk);
+                    unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos[1], kk) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)pos[0], kk);
+                    int t = 0;
+                    while (t < n_k) {
+                        const int ccx = (int)((uint32_t)cur & 0xffu), ccy = (int)(((uint32_t)cur >> 8) & 0xffu);
+                        const unsigned long long m3 = 7ull << (ccx - 1);
+                        const uint32_t m3lo = (uint32_t)m3, m3hi = (uint32_t)(m3 >> 32);
+                        const bool mine = (unsigned)(lane1 - ccy) < 3u;             // rows ccy - 1 .. ccy + 1
+                        const unsigned long long fresh3 = __ballot(mine && (((~vlo & m3lo) | (~vhi & m3hi)) != 0u));
+                        vlo = mine ? (vlo | m3lo) : vlo;
+                        vhi = mine ? (vhi | m3hi) : vhi;
+                        t++;
+                        if (!((mm & 1u) != 0u && fresh3 != 0ull)) break;
+                        mm >>= 1; cur >>= 16;
+                        if (t == 4) cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos[3], kk) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)pos[2], kk);
+                    }
+                    T = (lane == kk) ? t : T;
+                }
+            } else
             for (int kk = 0; kk < npiv; kk++) {
                 unsigned long long tr;
                 int qu, qv, info = 0;
