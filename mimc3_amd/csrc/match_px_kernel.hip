@@ -1746,48 +1746,59 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             unsigned long long ntr = 0ull;           // many-pivot configurations: the record of pivot kk + 1 (>= 64), read one pivot ahead
             int nqu = 0, nqv = 0, ninfo = 0;
             bool xcut = false;
-            // Register visited set, one lane per pivot: every lane first decodes ITS trajectory into scan centres (8 + 8 bits per
-            // scan, two per register) and a "this scan moved" mask -- in parallel, where the sequential loop used to decode the
-            // 4-bit codes scan by scan on the scalar unit; what stays sequential is one lane read, the 3 x 3-bit test-and-set on
-            // the three row lanes and the continue test per scan (the chain was 19 k of a point's 126 k cycles at BASELINE C2).
+            // Register visited set, one lane per pivot: every lane first turns ITS trajectory into move deltas (4 bits per scan) -- in
+            // parallel, where the sequential loop used to decode the 4-bit result codes scan by scan with a table on the scalar unit;
+            // what stays sequential is three lane reads per pivot and, per scan, the 3 x 3-bit test-and-set on the three row lanes,
+            // the continue test and the step (the chain was 19 k of a point's 126 k cycles at BASELINE C2; 12 k now).
             constexpr bool kFastReplay = MIMC3_FAST_REPLAY && !C::MANYP;
-            constexpr int kFastScans = 8;                 // scans per pivot the decoded form holds (4 registers); longer speculations: the loop below
-            if (kFastReplay && regmask && __ballot(nsc > kFastScans) == 0ull) {
-                uint32_t pos[kFastScans / 2] = {0u, 0u, 0u, 0u};
-                uint32_t mvmask = 0u;
-                {
-                    int x = start_u - OCW, y = start_v - OCW;
+            if (kFastReplay && regmask) {
+                if (p.stats && tid == 0) p.stats[kStatW * (size_t)blockIdx.x + 14] += 1;
+                // lane k: pivot k's moves as 4 bits per scan, (du + 1) | (dv + 1) << 2 -- 5 = the scan did not move
+                uint32_t dlo = 0u, dhi = 0u;
 #pragma unroll
-                    for (int t = 0; t < kFastScans; t++) {
-                        if (__ballot(nsc > t) == 0ull) break;
-                        const uint32_t code = (uint32_t)(traj >> (4 * t)) & 15u;
-                        pos[t >> 1] |= ((uint32_t)x | ((uint32_t)y << 8)) << (16 * (t & 1));
-                        const bool moved = (code - 1u) < 9u && code != 5u;
-                        const int mv = (int)code - 1, q3 = (mv * 11) >> 5;
-                        x += moved ? q3 - 1 : 0; y += moved ? (mv - 3 * q3) - 1 : 0;
-                        mvmask |= moved ? (1u << t) : 0u;
-                    }
+                for (int t = 0; t < kSpecRounds; t++) {
+                    if (__ballot(nsc > t) == 0ull) break;
+                    const uint32_t code = (uint32_t)(traj >> (4 * t)) & 15u;
+                    const bool moved = (code - 1u) < 9u && code != 5u;
+                    const uint32_t mv = code - 1u, q3 = (mv * 11u) >> 5;
+                    const uint32_t d = moved ? (q3 | ((mv - 3u * q3) << 2)) : 5u;
+                    if (t < 8) dlo |= d << (4 * (t & 7)); else dhi |= d << (4 * (t & 7));
                 }
                 const int lane1 = lane + 1;
+                const uint32_t head = (uint32_t)(start_u - OCW) | ((uint32_t)(start_v - OCW) << 8) | ((uint32_t)nsc << 16);
                 for (int kk = 0; kk < npiv; kk++) {
-                    const int n_k = __builtin_amdgcn_readlane(nsc, kk);
-                    uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mvmask, kk);
-                    unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos[1], kk) << 32) |
-                                             (uint32_t)__builtin_amdgcn_readlane((int)pos[0], kk);
+                    const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)head, kk);
+                    const int n_k = (int)(hd >> 16);
+                    int ccx = (int)(hd & 0xffu), ccy = (int)((hd >> 8) & 0xffu);
+                    unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, kk) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)dlo, kk);
                     int t = 0;
                     while (t < n_k) {
-                        const int ccx = (int)((uint32_t)cur & 0xffu), ccy = (int)(((uint32_t)cur >> 8) & 0xffu);
                         const unsigned long long m3 = 7ull << (ccx - 1);
                         const uint32_t m3lo = (uint32_t)m3, m3hi = (uint32_t)(m3 >> 32);
-                        const bool mine = (unsigned)(lane1 - ccy) < 3u;             // rows ccy - 1 .. ccy + 1
-                        const unsigned long long fresh3 = __ballot(mine && (((~vlo & m3lo) | (~vhi & m3hi)) != 0u));
-                        vlo = mine ? (vlo | m3lo) : vlo;
-                        vhi = mine ? (vhi | m3hi) : vhi;
+                        // rows ccy - 1 .. ccy + 1 (lanes ccy - 1 .. ccy + 1) test and set their three bits; fresh3 = the lanes that held an
+                        // unvisited one.  Written out: the compiler keeps the wave-uniform values of this chain in vector registers
+                        // and rebuilds every mask as 0 / 1 values (33 instructions per scan instead of these 10).
+                        unsigned long long fresh3, sv;
+                        uint32_t tmp;
+                        asm volatile("v_subrev_u32_e32 %[tmp], %[y], %[l1]\n\t"
+                                     "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
+                                     "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                     "v_bitop3_b32 %[tmp], %[mlo], %[vlo], %[mlo] bitop3:0x30\n\t"      // m3lo & ~vlo
+                                     "v_bitop3_b32 %[tmp], %[mhi], %[tmp], %[vhi] bitop3:0xdc\n\t"      // | (m3hi & ~vhi)
+                                     "v_cmp_ne_u32_e32 vcc, 0, %[tmp]\n\t"
+                                     "v_or_b32_e32 %[vlo], %[mlo], %[vlo]\n\t"
+                                     "v_or_b32_e32 %[vhi], %[mhi], %[vhi]\n\t"
+                                     "s_mov_b64 exec, %[sv]\n\t"
+                                     "s_mov_b64 %[fr], vcc"
+                                     : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [fr] "=s"(fresh3), [vlo] "+v"(vlo), [vhi] "+v"(vhi)
+                                     : [y] "s"(ccy), [l1] "v"(lane1), [mlo] "s"(m3lo), [mhi] "s"(m3hi)
+                                     : "vcc", "scc");
                         t++;
-                        if (!((mm & 1u) != 0u && fresh3 != 0ull)) break;
-                        mm >>= 1; cur >>= 16;
-                        if (t == 4) cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos[3], kk) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readlane((int)pos[2], kk);
+                        const uint32_t d = (uint32_t)cur & 15u;
+                        if (d == 5u || fresh3 == 0ull) break;
+                        ccx += (int)(d & 3u) - 1; ccy += (int)(d >> 2) - 1;
+                        cur >>= 4;
                     }
                     T = (lane == kk) ? t : T;
                 }
@@ -2205,6 +2216,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
         }
         fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches; null lists in use %.3f of points, %.0f window / %.0f chip entries per point\n",
                 (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N, (double)h[11] / a.N, (double)h[12] / a.N, (double)h[13] / a.N);
+        fprintf(stderr, "[mimc3 u8 stats] replay on pre-decoded scan centres: %.3f of points\n", (double)h[14] / a.N);
     }
     return hipGetLastError();
 }
