@@ -57,6 +57,9 @@
 #ifndef MIMC3_FAST_REPLAY
 #define MIMC3_FAST_REPLAY 1     // exact replay on scan centres the lanes decoded beforehand (register visited set, <= 64 pivots)
 #endif
+#ifndef MIMC3_WIDE_REPLAY
+#define MIMC3_WIDE_REPLAY 1     // big chips: register visited set for cell grids up to 96 x 128
+#endif
 #ifndef MIMC3_GC
 #define MIMC3_GC 1              // six-sum body with compile-time chip masks for null-free chips
 #endif
@@ -1751,7 +1754,16 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // what stays sequential is three lane reads per pivot and, per scan, the 3 x 3-bit test-and-set on the three row lanes,
             // the continue test and the step (the chain was 19 k of a point's 126 k cycles at BASELINE C2; 12 k now).
             constexpr bool kFastReplay = MIMC3_FAST_REPLAY && !C::MANYP;
-            if (kFastReplay && regmask) {
+            // big chips: cell grids of up to 96 x 128 (BASELINE C4: 70 x 70) keep the visited set in registers too -- three column
+            // words per row, lane r holding rows r and r + 64 -- instead of LDS bit words read and OR-ed inside the chain
+            // (only in the compact LDS form, which is what large windows run: in the regular big-chip kernels the six extra registers
+            //  cost 2-3 % at BASELINE C2's geometry, where every grid fits 64 x 64 -- u8 ocw 30 10.92 vs 10.66 ms, d/dx ocw 40 19.33 vs
+            //  18.76; BASELINE C4: 161.5 -> 158.6 ms)
+            constexpr bool kWideReplay = kFastReplay && MIMC3_WIDE_REPLAY && C::COMPACT;
+            const bool regmask2 = kWideReplay && !regmask && pt.csx <= 96 && pt.csy <= 128;
+            uint32_t va2 = 0u, vb0 = 0u, vb1 = 0u, vb2 = 0u;
+            (void)va2; (void)vb0; (void)vb1; (void)vb2;
+            if (kFastReplay && (regmask || regmask2)) {
                 if (p.stats && tid == 0) p.stats[kStatW * (size_t)blockIdx.x + 14] += 1;
                 // lane k: pivot k's moves as 4 bits per scan, (du + 1) | (dv + 1) << 2 -- 5 = the scan did not move
                 uint32_t dlo = 0u, dhi = 0u;
@@ -1774,13 +1786,48 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                                              (uint32_t)__builtin_amdgcn_readlane((int)dlo, kk);
                     int t = 0;
                     while (t < n_k) {
-                        const unsigned long long m3 = 7ull << (ccx - 1);
-                        const uint32_t m3lo = (uint32_t)m3, m3hi = (uint32_t)(m3 >> 32);
                         // rows ccy - 1 .. ccy + 1 (lanes ccy - 1 .. ccy + 1) test and set their three bits; fresh3 = the lanes that held an
                         // unvisited one.  Written out: the compiler keeps the wave-uniform values of this chain in vector registers
                         // and rebuilds every mask as 0 / 1 values (33 instructions per scan instead of these 10).
                         unsigned long long fresh3, sv;
                         uint32_t tmp;
+                        if (kWideReplay && regmask2) {
+                            const int sh = ccx - 1;
+                            const unsigned long long w01 = sh < 64 ? (7ull << (sh & 63)) : 0ull, w12 = sh >= 32 ? (7ull << ((sh - 32) & 63)) : 0ull;
+                            const uint32_t m0 = (uint32_t)w01, m1 = sh < 32 ? (uint32_t)(w01 >> 32) : (uint32_t)w12, m2 = (uint32_t)(w12 >> 32);
+                            const int lane65 = lane + 65;
+                            unsigned long long frA;
+                            asm volatile("v_subrev_u32_e32 %[tmp], %[y], %[l1]\n\t"
+                                         "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
+                                         "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m0], %[a0], %[m0] bitop3:0x30\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m1], %[tmp], %[a1] bitop3:0xdc\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m2], %[tmp], %[a2] bitop3:0xdc\n\t"
+                                         "v_cmp_ne_u32_e32 vcc, 0, %[tmp]\n\t"
+                                         "v_or_b32_e32 %[a0], %[m0], %[a0]\n\t"
+                                         "v_or_b32_e32 %[a1], %[m1], %[a1]\n\t"
+                                         "v_or_b32_e32 %[a2], %[m2], %[a2]\n\t"
+                                         "s_mov_b64 exec, %[sv]\n\t"
+                                         "s_mov_b64 %[fa], vcc\n\t"
+                                         "v_subrev_u32_e32 %[tmp], %[y], %[l65]\n\t"
+                                         "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
+                                         "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m0], %[b0], %[m0] bitop3:0x30\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m1], %[tmp], %[b1] bitop3:0xdc\n\t"
+                                         "v_bitop3_b32 %[tmp], %[m2], %[tmp], %[b2] bitop3:0xdc\n\t"
+                                         "v_cmp_ne_u32_e32 vcc, 0, %[tmp]\n\t"
+                                         "v_or_b32_e32 %[b0], %[m0], %[b0]\n\t"
+                                         "v_or_b32_e32 %[b1], %[m1], %[b1]\n\t"
+                                         "v_or_b32_e32 %[b2], %[m2], %[b2]\n\t"
+                                         "s_mov_b64 exec, %[sv]\n\t"
+                                         "s_or_b64 %[fr], %[fa], vcc"
+                                         : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [fa] "=&s"(frA), [fr] "=s"(fresh3), [a0] "+v"(vlo), [a1] "+v"(vhi), [a2] "+v"(va2),
+                                           [b0] "+v"(vb0), [b1] "+v"(vb1), [b2] "+v"(vb2)
+                                         : [y] "s"(ccy), [l1] "v"(lane1), [l65] "v"(lane65), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2)
+                                         : "vcc", "scc");
+                        } else {
+                        const unsigned long long m3 = 7ull << (ccx - 1);
+                        const uint32_t m3lo = (uint32_t)m3, m3hi = (uint32_t)(m3 >> 32);
                         asm volatile("v_subrev_u32_e32 %[tmp], %[y], %[l1]\n\t"
                                      "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
                                      "s_and_saveexec_b64 %[sv], vcc\n\t"
@@ -1794,6 +1841,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                                      : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [fr] "=s"(fresh3), [vlo] "+v"(vlo), [vhi] "+v"(vhi)
                                      : [y] "s"(ccy), [l1] "v"(lane1), [mlo] "s"(m3lo), [mhi] "s"(m3hi)
                                      : "vcc", "scc");
+                        }
                         t++;
                         const uint32_t d = (uint32_t)cur & 15u;
                         if (d == 5u || fresh3 == 0ull) break;
@@ -1865,6 +1913,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             if (regmask && lane < pt.csy) {   // publish the visited rows for the fit (csx <= 64: vpitch is 32 or 64)
                 vis[(lane * vpitch) >> 5] = vlo;
                 if (vpitch > 32) vis[((lane * vpitch) >> 5) + 1] = vhi;
+            }
+            if (kWideReplay && regmask2) {        // (up to three words per row; rows lane and lane + 64)
+                if (lane < pt.csy) { uint32_t *r = &vis[(lane * vpitch) >> 5]; r[0] = vlo; if (vpitch > 32) r[1] = vhi; if (vpitch > 64) r[2] = va2; }
+                if (lane + 64 < pt.csy) { uint32_t *r = &vis[((lane + 64) * vpitch) >> 5]; r[0] = vb0; if (vpitch > 32) r[1] = vb1; if (vpitch > 64) r[2] = vb2; }
             }
             MIMC3_STAMP(7)
             // lane k: where pivot k ended and with which maximum (:744-752): after the last updating scan
