@@ -1776,12 +1776,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const uint32_t d = moved ? (q3 | ((mv - 3u * q3) << 2)) : 5u;
                     if (t < 8) dlo |= d << (4 * (t & 7)); else dhi |= d << (4 * (t & 7));
                 }
-                const int lane1 = lane + 1;
                 const uint32_t head = (uint32_t)(start_u - OCW) | ((uint32_t)(start_v - OCW) << 8) | ((uint32_t)nsc << 16);
                 for (int kk = 0; kk < npiv; kk++) {
                     const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)head, kk);
                     const int n_k = (int)(hd >> 16);
-                    int ccx = (int)(hd & 0xffu), ccy = (int)((hd >> 8) & 0xffu);
+                    int ccx = (int)(hd & 0xffu), cy1 = (int)((hd >> 8) & 0xffu) - 1;      // centre column, centre row - 1
                     unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, kk) << 32) |
                                              (uint32_t)__builtin_amdgcn_readlane((int)dlo, kk);
                     int t = 0;
@@ -1795,7 +1794,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                             const int sh = ccx - 1;
                             const unsigned long long w01 = sh < 64 ? (7ull << (sh & 63)) : 0ull, w12 = sh >= 32 ? (7ull << ((sh - 32) & 63)) : 0ull;
                             const uint32_t m0 = (uint32_t)w01, m1 = sh < 32 ? (uint32_t)(w01 >> 32) : (uint32_t)w12, m2 = (uint32_t)(w12 >> 32);
-                            const int lane65 = lane + 65;
+                            const int lane64 = lane + 64;
                             unsigned long long frA;
                             asm volatile("v_subrev_u32_e32 %[tmp], %[y], %[l1]\n\t"
                                          "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
@@ -1823,7 +1822,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                                          "s_or_b64 %[fr], %[fa], vcc"
                                          : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [fa] "=&s"(frA), [fr] "=s"(fresh3), [a0] "+v"(vlo), [a1] "+v"(vhi), [a2] "+v"(va2),
                                            [b0] "+v"(vb0), [b1] "+v"(vb1), [b2] "+v"(vb2)
-                                         : [y] "s"(ccy), [l1] "v"(lane1), [l65] "v"(lane65), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2)
+                                         : [y] "s"(cy1), [l1] "v"(lane), [l65] "v"(lane64), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2)
                                          : "vcc", "scc");
                         } else {
                         const unsigned long long m3 = 7ull << (ccx - 1);
@@ -1839,14 +1838,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                                      "s_mov_b64 exec, %[sv]\n\t"
                                      "s_mov_b64 %[fr], vcc"
                                      : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [fr] "=s"(fresh3), [vlo] "+v"(vlo), [vhi] "+v"(vhi)
-                                     : [y] "s"(ccy), [l1] "v"(lane1), [mlo] "s"(m3lo), [mhi] "s"(m3hi)
+                                     : [y] "s"(cy1), [l1] "v"(lane), [mlo] "s"(m3lo), [mhi] "s"(m3hi)
                                      : "vcc", "scc");
                         }
                         t++;
                         const uint32_t d = (uint32_t)cur & 15u;
-                        if (d == 5u || fresh3 == 0ull) break;
-                        ccx += (int)(d & 3u) - 1; ccy += (int)(d >> 2) - 1;
                         cur >>= 4;
+                        ccx += (int)(d & 3u) - 1; cy1 += (int)(d >> 2) - 1;          // (d = 5, no move: + 0)
+                        if (fresh3 == 0ull) break;
+                        if (d == 5u) break;
                     }
                     T = (lane == kk) ? t : T;
                 }
