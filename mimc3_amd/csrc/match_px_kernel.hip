@@ -43,8 +43,8 @@
 #define MIMC3_XY_ACC 2          // independent dot4 chains of the sxy-only body (tuning switch)
 #endif
 #ifndef MIMC3_SAT_DEFER
-#define MIMC3_SAT_DEFER 0       // table look-ups of a batch: keep the four corners in registers, combine them in the finish (measured: the
-#endif                          // eight registers cost more in spills than the early wait, 3.26 vs 3.13 ms)
+#define MIMC3_SAT_DEFER -1      // table look-ups of a batch: keep the four corners in registers, combine them in the finish.  -1 = per config
+#endif                          // (PxCfg::SAT_DEFER), 0 / 1 = never / always (A/B builds)
 #ifndef MIMC3_WN
 #define MIMC3_WN 1              // window-null cells of a clean chip: three sums + table instead of six
 #endif
@@ -539,6 +539,10 @@ struct PxCfg {
     //     a look-up costs a second, dependent LDS access;
     //   * the null lists hold 16-bit entries (window coordinates below 256: checked at launch).
     static constexpr bool COMPACT = COMPACT_;
+    // the table corners of a batch stay in registers until its finish pass (the look-up's latency hides behind the evaluation rounds,
+    // eight registers more are live across them): pays on the one-wave u8 kernels (BASELINE C2: 2.86 -> 2.83 ms, ocw 7 2.05 -> 2.03),
+    // costs where registers are short (u8 ocw 40 13.22 -> 13.38, integral f32 ocw 16 8.34 -> 8.59)
+    static constexpr bool SAT_DEFER = std::is_same<P_, PxU8>::value && NW_ == 1;
     static constexpr int MINW = MINW_;                       // occupancy target, waves per SIMD
     static constexpr int OCW = OCW_, LPC = LPC_;
     static constexpr int NW = NW_, NT = 64 * NW_;            // waves / threads per grid point (one workgroup)
@@ -1320,21 +1324,27 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         }
         // clean boxes of the 3x3 from three column tests and three row tests (bit j = 3 * column + row, as above): a box is
         // clean if its column range or its row range misses the null bounding box, and it does not touch the T4 row / column
-        uint32_t row_ok = 0u, row_t4 = 0u;
+        // (the T4 row / column is cell csy - 2 / csx - 2: only a 3x3 centred on csy - 3 / csx - 3 holds it, as its last row / column)
+        const uint32_t row_t4 = (!full_win && cy0 == pt.csy - 3) ? 4u : 0u;
+        const bool col_t4 = !full_win && cx0 == pt.csx - 3;
+        uint32_t cl;
+        if (win_clean) {                                     // (wave-uniform: 46 % of BASELINE C2's windows hold no null)
+            cl = (7u & ~row_t4) * (col_t4 ? 0x09u : 0x49u);
+        } else {
+            uint32_t row_ok = 0u;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int cy = cy0 + k - 1;
-            row_ok |= (win_clean || cy > nby1 || cy + CW - 1 < nby0) ? (1u << k) : 0u;
-            row_t4 |= (!full_win && cy == pt.csy - 2) ? (1u << k) : 0u;
-        }
-        uint32_t cl = 0u;
+            for (int k = 0; k < 3; k++) {
+                const int cy = cy0 + k - 1;
+                row_ok |= (cy > nby1 || cy + CW - 1 < nby0) ? (1u << k) : 0u;
+            }
+            cl = 0u;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int cx = cx0 + i - 1;
-            const bool col_ok = win_clean || cx > nbx1 || cx + CW - 1 < nbx0;
-            const bool col_t4 = !full_win && cx == pt.csx - 2;
-            const uint32_t part = col_t4 ? 0u : ((col_ok ? 7u : row_ok) & ~row_t4);
-            cl |= part << (3 * i);
+            for (int i = 0; i < 3; i++) {
+                const int cx = cx0 + i - 1;
+                const bool col_ok = cx > nbx1 || cx + CW - 1 < nbx0;
+                const uint32_t part = (i == 2 && col_t4) ? 0u : ((col_ok ? 7u : row_ok) & ~row_t4);
+                cl |= part << (3 * i);
+            }
         }
         const uint32_t wa = won & cl, wb = won & ~cl;
         const int na = __popc(wa), nb = __popc(wb);
@@ -1368,6 +1378,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     // ADD their partial sums into the cell's parking slot with LDS atomics (no return value: nothing waits on them; integer
     // adds commute, so the result is exact and deterministic).  The slots are zero between batches.
     constexpr bool kAPark = (C::LPC >= 32) && P::INTEGER;
+    constexpr bool kSatDefer = MIMC3_SAT_DEFER < 0 ? C::SAT_DEFER : (MIMC3_SAT_DEFER != 0);
     auto evaluate = [&](const uint16_t *ids, int dir, int cnt, int mode) __attribute__((always_inline)) {
         const bool dirty_list = (mode == M_GENERAL);
         // dirty boxes of a null-free chip, planes with a table: the WN body (three sums) instead of the six-sum GENERAL body --
@@ -1403,7 +1414,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     const uint32_t pk = ids[dir * (b0 + tid)];
                     const SatT *r0 = sat_win + (size_t)(wv0 + (int)((pk >> 8) & 0xffu)) * p.sat_ws + (wu0 + (int)(pk & 0xffu)), *r1 = r0 + (size_t)CW * p.sat_ws;
                     q00 = r0[0]; q01 = r0[CW]; q10 = r1[0]; q11 = r1[CW];
-                    if (!MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
+                    if (!kSatDefer) cellQ = q11 - q01 - q10 + q00;
                     if constexpr (kSatZ) {        // the nulls of a dirty box: n of a WN cell; the offset policy's unit conversion (its unmasked sums count a null as 0, not as -k)
                         if (dirty_list) cellZ = (int)sat_box(satz_win, p.sat_ws, wu0 + (int)(pk & 0xffu), wv0 + (int)((pk >> 8) & 0xffu), CW, CW);
                     }
@@ -1413,7 +1424,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             // table knows whether it holds a null at all.  Boxes without one skip the walk over the window-null list (their
             // corrections to n, sx, sxx are zero): the finishing lanes publish one flag per cell of the batch.
             [[maybe_unused]] unsigned char *nzf = reinterpret_cast<unsigned char *>(&qcnt[24]);       // [kSumBatch]
-            constexpr bool kNullFlags = C::SPARSE && kSat && !MIMC3_SAT_DEFER && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
+            constexpr bool kNullFlags = C::SPARSE && kSat && !kSatDefer && kSumBatch <= 32 && MIMC3_NULL_FLAGS;
             // (pays where a box is a small part of the window -- BASELINE C4: 65^2 of 133^2, many dirty-list boxes hold no null, -1.8 % --
             //  and costs a barrier per batch where it is not: C2's 81^2 of 113^2, +1 %)
             const bool flags_on = kNullFlags && 3 * CW * CW <= pt.Dx2 * pt.Dy2;
@@ -1555,7 +1566,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             }
             __syncthreads();
             if (tid < nb) {
-                if (MIMC3_SAT_DEFER) cellQ = q11 - q01 - q10 + q00;
+                if (kSatDefer) cellQ = q11 - q01 - q10 + q00;
                 const uint32_t pk = ids[dir * (b0 + tid)];
                 const int cx = (int)(pk & 0xffu), cy = (int)((pk >> 8) & 0xffu);
                 Store *sp = sums + 6 * tid;
