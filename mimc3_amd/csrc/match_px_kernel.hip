@@ -1586,6 +1586,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                     if (wn_cell) {
                         Sum ty = 0, tyy = 0;
                         const int z = kSatZ ? cellZ : P::sat_nulls(cellQ);
+                        if (p.stats && z == 0) atomicAdd(&p.stats[kStatW * (size_t)blockIdx.x + 15], 1ull);
                         P::sat_win_sums(ty, tyy, cellQ, z, kb, C::NPX, sc_win);
                         v[0] = (Store)(uint32_t)(C::NPX - z); v[2] = P::bits(ty); v[4] = P::bits(tyy);
                     }
@@ -2279,7 +2280,7 @@ static hipError_t launch_cfg(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
         }
         fprintf(stderr, "[mimc3 u8 stats] cells/point: clean-box %.1f dirty-box %.1f in %.1f evaluation batches; null lists in use %.3f of points, %.0f window / %.0f chip entries per point\n",
                 (double)h[8] / a.N, (double)h[9] / a.N, (double)h[10] / a.N, (double)h[11] / a.N, (double)h[12] / a.N, (double)h[13] / a.N);
-        fprintf(stderr, "[mimc3 u8 stats] replay on pre-decoded scan centres: %.3f of points\n", (double)h[14] / a.N);
+        fprintf(stderr, "[mimc3 u8 stats] replay on pre-decoded scan centres: %.3f of points; dirty-list boxes without a null: %.2f per point\n", (double)h[14] / a.N, (double)h[15] / a.N);
     }
     return hipGetLastError();
 }
