@@ -15,6 +15,14 @@ def cases():
                                                 noise_dn=3, offset=(2, -1))
     yield "ocw32_long_corridor", synth.make_small(seed=73, shift=(9, -9), angle_deg=45.0, ocw=32, dimx=12, dimy=10, h=640, w=640, null_frac=0.03,
                                                  noise_dn=2, speed=5200.0, margin=110)
+    # cell grids beyond 64 x 64 (BASELINE C4's are 70 x 70): the compact form keeps the replay's visited set in registers up to
+    # 96 x 128 (three column words per row, rows r and r + 64 on lane r), LDS bit words beyond; the regular form always LDS
+    yield "ocw32_grid72x72", synth.make_small(seed=75, shift=(10, -10), angle_deg=45.0, ocw=32, dimx=10, dimy=8, h=700, w=700, null_frac=0.03,
+                                             noise_dn=2, speed=6400.0, margin=125)
+    yield "ocw30_grid8x110", synth.make_small(seed=76, shift=(0, -12), angle_deg=92.0, ocw=30, dimx=10, dimy=8, h=760, w=520, null_frac=0.03,
+                                             noise_dn=2, speed=7200.0, margin=130)
+    yield "ocw30_grid132x10", synth.make_small(seed=77, shift=(14, 0), angle_deg=2.0, ocw=30, dimx=8, dimy=8, h=520, w=860, null_frac=0.02,
+                                              noise_dn=2, speed=9000.0, margin=140)
     yield "ocw30_edge_windows", synth.make_small(seed=74, shift=(2, 2), angle_deg=-60.0, ocw=30, dimx=12, dimy=10, h=420, w=440, null_frac=0.02,
                                                 noise_dn=2, speed=2500.0, margin=33)
 

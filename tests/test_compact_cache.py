@@ -14,11 +14,14 @@ from conftest import ROOT, assert_bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def test_forced_compact_form_is_bit_identical(oracle, tmp_path):
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_forced_compact_form_is_bit_identical(oracle, tmp_path, compact):
+    """compact = 1: the compact form on every launch; 0: never (the same cases on the regular form: its big cell grids keep the
+    visited set of the exact replay in LDS)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import compact_worker
     out = str(tmp_path / "r.npz")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compact_worker.py"), out], env=dict(os.environ, MIMC3_COMPACT="1", MIMC3_LDS_DEBUG="1"),
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compact_worker.py"), out], env=dict(os.environ, MIMC3_COMPACT=compact, MIMC3_LDS_DEBUG="1"),
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     r = np.load(out)
