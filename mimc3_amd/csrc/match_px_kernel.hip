@@ -835,7 +835,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
     float *vals = reinterpret_cast<float *>(smem + (C::COMPACT ? p.lds_off_vals : 0));
     (void)map16; (void)vals;
     if constexpr (C::COMPACT) { for (int i = tid; i < (vpitchc * (pt.csy - 2) + 1) / 2; i += NT) reinterpret_cast<uint32_t *>(val)[i] = 0u; }
-    else { for (int i = tid; i < vpitchc * (pt.csy - 2); i += NT) val[i] = kUnknown; }
+    else {
+        // (16 bytes per store: the carve is 16-byte aligned and whatever follows the cache within the last quad is cleared or written
+        //  later -- the visited bits start on their own 16-byte boundary)
+        const int ncw = vpitchc * (pt.csy - 2);
+        const float4 u4 = make_float4(kUnknown, kUnknown, kUnknown, kUnknown);
+        for (int i = tid; i < (ncw >> 2); i += NT) reinterpret_cast<float4 *>(val)[i] = u4;
+        if (tid < (ncw & 3)) val[(ncw & ~3) + tid] = kUnknown;
+    }
     auto cell_index = [&](int cx, int cy) __attribute__((always_inline)) -> int { return (cy - 1) * vpitchc + (cx - 1); };
     auto lookup = [&](int cx, int cy) __attribute__((always_inline)) -> float {
         if constexpr (C::COMPACT) {
@@ -1081,11 +1088,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         for (int c = tid; c < ndz; c += NT) *reinterpret_cast<uint32_t *>(W + wrows * pt.PW + 4 * c) = 0u;
         for (int r = tid; r < wrows; r += NT)
             for (int c = nd; c < ndz; c++) *reinterpret_cast<uint32_t *>(W + r * pt.PW + 4 * c) = 0u;
+        if (!(kSat && win_nulls == 0)) {             // (a window the table calls null-free was copied without looking: nothing to reduce)
         bad_win = wave_sum_i(bad_win); exc_win = wave_sum_i(exc_win);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             nbx0 = min(nbx0, __shfl_xor(nbx0, o, 64)); nbx1 = max(nbx1, __shfl_xor(nbx1, o, 64));
             nby0 = min(nby0, __shfl_xor(nby0, o, 64)); nby1 = max(nby1, __shfl_xor(nby1, o, 64));
+        }
         }
         if (NW > 1) {                                        // combine the waves' partial results through LDS
             if (lane == 0) {
