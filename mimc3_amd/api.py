@@ -643,10 +643,10 @@ class Context:
     def set_path(self, mode):
         """"auto" (0): u8 kernel when the pair is 8-bit integral, else the tiled f32 kernel, else the general
         one; "general" (1): force the general f32 kernel; "f32" (2): like auto but never the u8 kernel."""
-        _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1, "f32": 2, "u16": 3}.get(mode, mode)), "set_path")
+        _check(_lib.mimc3_ctx_set_path(self._h, {"auto": 0, "general": 1, "f32": 2, "u16": 3, "u8px": 4}.get(mode, mode)), "set_path")
 
     def last_path(self):
-        return {0: "general_f32", 1: "u8_exact", 2: "f32_tiled", 3: "u16_scaled", 4: "u8_offset"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
+        return {0: "general_f32", 1: "u8_exact", 2: "f32_tiled", 3: "u16_scaled", 4: "u8_offset", 5: "u8_mfma"}.get(int(_lib.mimc3_ctx_last_path(self._h)), "none")
 
     # -- timing -------------------------------------------------------------------------------
     def enable_timing(self, on=True):

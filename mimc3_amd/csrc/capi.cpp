@@ -54,6 +54,12 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // owned: a context's buffers go with the context (mimc3_ctx_destroy selects the device first), so a member added later cannot be
+    // forgotten there
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
 };
 
 struct mimc3_ctx {
@@ -81,8 +87,8 @@ struct mimc3_ctx {
     int fshift0 = 0, fshift1 = 0;      // pixel x 2^shift is the integer the table sums
     int32_t Wp = 0;
     bool u8_ok = false;                 // both images proven to be integers in [0,255]
-    int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel
-    int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel
+    int path_mode = 0;                  // 0 auto, 1 force the general f32 kernel, 2 no integer kernels, 3 no u8 kernel, 4 auto without the matrix-core kernel
+    int last_path = -1;                 // 0 general f32/f64 kernel, 1 exact u8 kernel, ... (mimc3_hip.h), 5 matrix-core u8 kernel
     DevBuf xy, puv, poff, out;          // matcher staging for the host-buffer entry point
     DevBuf pcor, pcnt, pext;            // device pivots: corridors [N] x 24 B, counts [N], extents + total (24 B)
     int32_t xy_stride = 6, xy_col = 2;  // where the matcher finds a point's (u, v) in its `xyuvav` argument: xyuvav rows, or (internal) a packed [N][2] array
@@ -110,6 +116,7 @@ struct mimc3_ctx {
     bool no_u8o = false;                // internal (CP stage): never try the per-point-offset u8 form on this context's pairs
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
+    DevBuf mxl[4];                      // matrix-core kernel: [0] null-list count, [1] rest-list count, then the two lists (one set per `lane`)
     int32_t win_half = 0;               // internal (CP stage): > 0 = the next matcher calls use a full (2*win_half+1)^2 search area
     mimc3_ctx *cp_child[4] = {nullptr, nullptr, nullptr, nullptr};   // CP stage: one context per image variant for its chip atlas (planes, kernel selection)
     DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
@@ -397,7 +404,7 @@ static int prepare_u8(mimc3_ctx *c, bool planes_built = false)
 
 extern "C" int mimc3_ctx_set_path(mimc3_ctx *c, int32_t mode)
 {
-    if (!c || mode < 0 || mode > 3) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
+    if (!c || mode < 0 || mode > 4) return mimc3::fail(MIMC3_EINVAL, "mimc3_ctx_set_path: bad argument");
     c->path_mode = mode;
     return 0;
 }
@@ -579,8 +586,9 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         return fn(probe, max_abs_piv_u, max_abs_piv_v, max_npiv, nullptr) == hipSuccess;
     };
     const bool px_ok = mimc3::match_u8_supported(ocw, reach_u, reach_v);
-    const bool want_u8 = c->path_mode == 0 && c->u8_ok && px_ok && fits(mimc3::launch_match_u8);
-    bool want_u16 = !want_u8 && (c->path_mode == 0 || c->path_mode == 3) && px_ok && fits(mimc3::launch_match_u16);
+    const bool auto_mode = c->path_mode == 0 || c->path_mode == 4;
+    const bool want_u8 = auto_mode && c->u8_ok && px_ok && fits(mimc3::launch_match_u8);
+    bool want_u16 = !want_u8 && (auto_mode || c->path_mode == 3) && px_ok && fits(mimc3::launch_match_u16);
     if (want_u16 && !c->u16_ok) {
         if (c->u8_ok && c->path_mode == 3 && !c->hpl_valid) {  // tests: 8-bit pairs are scaled integers too (shift 0)
             const size_t hb = sizeof(unsigned short) * (size_t)(c->H + 2 * mimc3::kU8Pad) * c->Wp;
@@ -619,13 +627,29 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         if (want_u8) {
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
             u.sat0 = c->sat0.p; u.sat1 = c->sat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
+            if (tables_needed && c->path_mode == 0 && mimc3::match_mx_supported(ocw, max_npiv, c->win_half)) {
+                // dense correlation surfaces on the matrix cores first; the points that kernel does not take (chips with nulls,
+                // corridors wider than its tile, ...) are redone by the register-tiled kernel in list mode, no host round trip
+                DevBuf &ml = c->mxl[c->lane];
+                HIP_TRY(ml.reserve(sizeof(int32_t) * (2 * (size_t)N + 2)));
+                HIP_TRY(hipMemsetAsync(ml.p, 0, 2 * sizeof(int32_t), s));
+                u.mx_null_count = static_cast<int32_t *>(ml.p); u.mx_rest_count = u.mx_null_count + 1;
+                u.mx_null_list = u.mx_null_count + 2; u.mx_rest_list = u.mx_null_list + N;
+                e = mimc3::launch_match_mx(u, s);
+                if (e == hipSuccess) {
+                    u.point_count = u.mx_rest_count; u.point_list = u.mx_rest_list;
+                    e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
+                }
+                c->last_path = 5;
+            } else {
             e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
             c->last_path = 1;
+            }
         } else if (want_u16) {
             u.p0 = static_cast<const unsigned char *>(c->hpl0.p); u.p1 = static_cast<const unsigned char *>(c->hpl1.p);
             u.scale0 = 1.0 / (double)(1 << c->shift0); u.scale1 = 1.0 / (double)(1 << c->shift1);
             u.sat0 = c->hsat0.p; u.sat1 = c->hsat1.p; u.satz0 = c->hsz0.p; u.satz1 = c->hsz1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
-            if (c->u8o_ok && c->u16_ok && c->path_mode == 0) {
+            if (c->u8o_ok && c->u16_ok && auto_mode) {
                 // u8 machinery through per-point offsets first; what does not fit is redone by the u16 kernel in list mode
                 HIP_TRY(failb.reserve(sizeof(int32_t) * ((size_t)N + 1)));
                 HIP_TRY(hipMemsetAsync(failb.p, 0, sizeof(int32_t), s));

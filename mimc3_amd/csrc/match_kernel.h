@@ -55,6 +55,8 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
     const int32_t *point_list, *point_count;   // list mode: workgroup b handles point_list[b], b < *point_count (nullptr = all N points)
     int32_t *fail_list, *fail_count;           // PxU8o only: points whose chip or window does not fit a local 8-bit range
+    // matrix-core kernel (match_mx_kernel.hip): points its clean form hands to its window-null form / points neither form takes
+    int32_t *mx_null_list, *mx_null_count, *mx_rest_list, *mx_rest_count;
     // LDS carve, filled by the launcher
     int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists
@@ -98,6 +100,10 @@ hipError_t launch_prep_f32(const float *img, int H, int W, float *plane, int Wp,
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v);
 hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
+// dense correlation surfaces on the matrix cores (8-bit planes with tables; match_mx_kernel.hip): takes the points whose cell grid
+// fits its tile and whose chip has no null, leaves the others in a.mx_rest_list for launch_match_u8 in list mode
+bool match_mx_supported(int ocw, int max_npiv, int win_half);
+hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream);
 
 // max_abs_u/v: max over points of |last pivot| per axis; max_npiv: max pivots per point.
 hipError_t launch_match_f32(MatchArgs a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);

@@ -1,0 +1,727 @@
+// match_mx_kernel.hip -- DLC/NCC matcher for gfx950 on the matrix cores: 8-bit imagery, DENSE correlation surfaces.
+//
+// Same contract as match_px_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842), for the points whose reachable cell grid
+// fits one 32 x 32 tile.  One wave64 = one grid point.  Instead of evaluating the cells a hill climb asks for (a request
+// queue, evaluation batches, a speculative climb that waits for them), the kernel builds the COMPLETE surface of the tile:
+//
+//   sxy[dy][s] = sum_r sum_k a[r][k] * b[r + dy][k + s]                              (MIMC_module.c:719-733, the product stream)
+//              = sum_r (W_r T_r)[dy][s]     W_r[dy][j] = b[r + dy][j]   A operand: 32 window rows, plain 16-byte LDS reads
+//                                           T_r[j][s]  = a[r][j - s]    B operand: the Toeplitz band of chip row r, 0 outside
+//   i.e. one v_mfma_i32_32x32x32_i8 per chip row and 32 window columns, all into ONE 32 x 32 i32 accumulator (exact integers).
+//   u8 -> i8:  a' = a - 128 (a ^ 0x80), b' = b - 128, Toeplitz padding a' = 0:
+//              sum ab = sum a'b' + 128 sum_box b + 128 sum a - 128^2 CW^2        (a null is a zero factor: no mask anywhere)
+//   * window-side sums  sy = sum_box b, syy = sum_box b^2  of every cell: row-box sums by MFMA against a band of ones
+//     (b^2 as two byte planes), then the vertical CW-row sums by a second MFMA against a band of ones (the row sums split
+//     into byte planes; an accumulator tile is the next MFMA's B operand as it stands: its rows are the K index);
+//   * window nulls (NULLS form): a null pixel q of the box takes a(q) out of n, sx, sxx.  With z = [b == 0] as the A operand
+//     the three corrections are three more correlations on the same pipe:  sum z (box count),  sum a z  (same B operand as
+//     sxy),  sum a^2 z  (a^2 as two byte planes of the CHIP operand).  The never-written last window row / column (T4) are
+//     zeros of the staged tile, i.e. nulls like any other; the clean form applies them in closed form (they take the chip's
+//     last column / row out of n, sx, sxx);
+//   * the NCC of all 1,024 cells (:734, f64, no contraction) -> one f32 surface in LDS;
+//   * the climb of every pivot on the complete surface (lane k = pivot k), the exact replay of the reference's sequential
+//     visited-set semantics (:691-753) and the 3x3 fit (:757-788) as in match_px_kernel.hip.
+// What this kernel does not take it hands on (device lists, no host round trip): points whose window holds nulls go from the
+// clean form to the NULLS form; chips with nulls, more than 64 pivots, pivot sets wider than the tile, climbs that leave the
+// tile or outlast the 16 recorded scans go to the register-tiled kernel (match_px_kernel.hip) in list mode.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
+#include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include "match_kernel.h"
+#include "sat_kernel.h"
+
+namespace mimc3 {
+
+namespace mx {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t alignb(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+
+// first-wins arg-max over the 16 lanes of a DPP row (lexicographic max on (value, -index)); VALU only
+__device__ __forceinline__ void argmax_row16(float &v, int &i)
+{
+#define MIMC3_MX_ARGMAX_STEP(ctrl)                                                                        \
+    {                                                                                                     \
+        const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, i, ctrl, 0xF, 0xF, true);                           \
+        const bool t = (ov > v) || (ov == v && oi < i);                                                   \
+        v = t ? ov : v; i = t ? oi : i;                                                                   \
+    }
+    MIMC3_MX_ARGMAX_STEP(0xB1) MIMC3_MX_ARGMAX_STEP(0x4E) MIMC3_MX_ARGMAX_STEP(0x141) MIMC3_MX_ARGMAX_STEP(0x140)
+#undef MIMC3_MX_ARGMAX_STEP
+}
+
+template <int OCW_, bool NULLS_>
+struct Cfg {
+    static constexpr int OCW = OCW_, CW = 2 * OCW_ + 1, NPX = CW * CW;
+    static constexpr bool NULLS = NULLS_;
+    static constexpr int KW = CW + 31;               // window columns (and rows) the 32 x 32 cells of a tile reach
+    static constexpr int KC = (KW + 31) / 32;        // MFMAs per chip row (K chunks of 32 window columns)
+    static constexpr int TW = 32 * KC;               // staged tile: bytes per row ...
+    static constexpr int PW = TW + 16;               // ... at a pitch of 16 x odd: the 16 lanes of a ds_read_b128 group hit 16 distinct slots
+    static constexpr int TH = 32 * KC;               // rows (the row tiles of the box sums read whole 32-row tiles; rows >= KW carry weight 0)
+    static constexpr int CD = (CW + 3) / 4;          // dwords per chip row
+    static constexpr int LASTN = CW - 4 * (CD - 1);  // valid bytes of a chip row's last dword
+    static constexpr int CP = (CW + 31 > TW ? ((CW + 31 + 3) & ~3) : TW);   // chip plane pitch: a row's right padding is the next row's left padding
+    static constexpr int CH0 = 32;                   // leading zeros (row 0's left padding)
+    static constexpr int CHB = (CH0 + CW * CP + 16 + 15) & ~15;             // one chip plane (+ the read-ahead of the last row's last lane)
+    static constexpr int NPL = NULLS_ ? 3 : 1;       // chip planes: a', and for the null corrections (a^2 & 255)', (a^2 >> 8)'
+    static constexpr int ND = 4 * KC + 1;            // dwords a lane reads for one chip row (its 16 KC bytes at a byte phase)
+    static constexpr int VP = 33;                    // pitch (words) of the NCC surface
+    static constexpr int LDS_W = TH * PW;
+    static constexpr int LDS_VAL = 4 * 32 * VP;
+    static constexpr int OFF_CH = (LDS_W > LDS_VAL ? LDS_W : LDS_VAL);      // the surface reuses the tile's bytes once the sums are in registers
+    static constexpr int OFF_VIS = OFF_CH + NPL * CHB;
+    static constexpr int LDS = OFF_VIS + 128;
+    static constexpr int MINW = NULLS_ ? 2 : 3;            // occupancy target, waves per SIMD
+};
+
+// The constant band operands, one table per chip size (constant-initialised device data):
+//   hb[c][lane] : B operand of the row-box sums -- lane (s = lane & 31, h = lane >> 5), byte i of chunk c <-> window column
+//                 x = 16 KC h + 16 c + i :  1 if s <= x < s + CW
+//   vb[t][lane] : A operand of the vertical sums over row tile t -- lane (dy = lane & 31, h), byte i <-> K slot (h, i) <->
+//                 tile row y = 32 t + 8 (i >> 2) + 4 h + (i & 3) (where the accumulator layout of the row sums puts it):
+//                 1 if dy <= y < dy + CW
+template <int CW, int KC>
+struct alignas(16) Bands {
+    uint32_t hb[KC][64][4], vb[KC][64][4];
+    constexpr Bands() : hb(), vb()
+    {
+        for (int c = 0; c < KC; c++)
+            for (int l = 0; l < 64; l++) {
+                const int s = l & 31, h = l >> 5;
+                for (int i = 0; i < 16; i++) {
+                    const int x = 16 * KC * h + 16 * c + i;
+                    if (s <= x && x < s + CW) hb[c][l][i >> 2] |= 1u << (8 * (i & 3));
+                    const int y = 32 * c + 8 * (i >> 2) + 4 * h + (i & 3);
+                    if (s <= y && y < s + CW) vb[c][l][i >> 2] |= 1u << (8 * (i & 3));
+                }
+            }
+    }
+};
+template <int CW, int KC> __device__ const Bands<CW, KC> kBands{};
+
+constexpr int kStatW = 8;
+
+// u8 pixels back from the signed bytes of an A operand, squared, split into the byte planes (x^2 & 255) and (x^2 >> 8), as signed bytes
+__device__ __forceinline__ void squares(const v4i &a, v4i &lo, v4i &hi)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t x = (uint32_t)a[k] ^ 0x80808080u;
+        const uint32_t s0 = (x & 0xffu) * (x & 0xffu), s1 = ((x >> 8) & 0xffu) * ((x >> 8) & 0xffu);
+        const uint32_t s2 = ((x >> 16) & 0xffu) * ((x >> 16) & 0xffu), s3 = (x >> 24) * (x >> 24);
+        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);    // [s0.b0, s1.b0, s0.b1, s1.b1]
+        lo[k] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        hi[k] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+    }
+}
+// 1 in every byte of the A operand that is a null pixel (b == 0, i.e. b' == 0x80)
+__device__ __forceinline__ v4i nullbytes(const v4i &a)
+{
+    v4i z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t x = (uint32_t)a[k] ^ 0x80808080u;
+        const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;           // 0x80 in every non-zero byte
+        z[k] = (int)((nz ^ 0x80808080u) >> 7);
+    }
+    return z;
+}
+// byte planes 0 and 1 of the 16 row sums of an accumulator tile (values < 2^16), as the B operand of the vertical sums (signed bytes)
+__device__ __forceinline__ void planes2(const v16i &R, v4i &p0, v4i &p1)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t01 = perm((uint32_t)R[4 * q + 1], (uint32_t)R[4 * q], 0x05010400u), t23 = perm((uint32_t)R[4 * q + 3], (uint32_t)R[4 * q + 2], 0x05010400u);
+        p0[q] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        p1[q] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+    }
+}
+// ... planes 0, 1, 2 (values < 2^24)
+__device__ __forceinline__ void planes3(const v16i &R, v4i &p0, v4i &p1, v4i &p2)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t r0 = (uint32_t)R[4 * q], r1 = (uint32_t)R[4 * q + 1], r2 = (uint32_t)R[4 * q + 2], r3 = (uint32_t)R[4 * q + 3];
+        const uint32_t t01 = perm(r1, r0, 0x05010400u), t23 = perm(r3, r2, 0x05010400u);
+        const uint32_t u01 = perm(r1, r0, 0x07030602u), u23 = perm(r3, r2, 0x07030602u);     // [r0.b2, r1.b2, r0.b3, r1.b3]
+        p0[q] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        p1[q] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+        p2[q] = (int)(perm(u23, u01, 0x05040100u) ^ 0x80808080u);
+    }
+}
+// ... plane 0 alone (values < 128: no sign to care about)
+__device__ __forceinline__ void planes1(const v16i &R, v4i &p0)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t01 = perm((uint32_t)R[4 * q + 1], (uint32_t)R[4 * q], 0x05010400u), t23 = perm((uint32_t)R[4 * q + 3], (uint32_t)R[4 * q + 2], 0x05010400u);
+        p0[q] = (int)perm(t23, t01, 0x05040100u);
+    }
+}
+
+#define MIMC3_MX_STAMP(i)                                                                      \
+    if (p.stats) {                                                                             \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
+        if (lane == 0) p.stats[kStatW * (size_t)blockIdx.x + i] += t_now - t_prev;             \
+        t_prev = t_now;                                                                        \
+    }
+
+template <class C>
+__global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
+{
+    constexpr int OCW = C::OCW, CW = C::CW, NPX = C::NPX, KC = C::KC, PW = C::PW, CP = C::CP, CH0 = C::CH0, VP = C::VP;
+    constexpr bool NULLS = C::NULLS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+    unsigned char *WT = smem;
+    float *val = reinterpret_cast<float *>(smem);                       // [32][VP] NCC surface (over the tile, once it is consumed)
+    unsigned char *CH = smem + C::OFF_CH;                               // chip planes
+    uint32_t *vis = reinterpret_cast<uint32_t *>(smem + C::OFF_VIS);    // visited bits of the 32 tile rows
+    unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int lane = threadIdx.x;
+
+    int gidx = blockIdx.x;
+    if (p.point_list) {                                      // list mode: the points another kernel handed over
+        if (gidx >= *p.point_count) return;
+        gidx = p.point_list[gidx];
+    } else {
+        const int nb = gridDim.x, per = nb >> 3;
+        if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);   // XCD-contiguous point order
+    }
+    if (gidx >= p.N) return;
+    auto hand_on = [&](int32_t *list, int32_t *count) __attribute__((always_inline)) {
+        if (lane == 0) list[atomicAdd(count, 1)] = gidx;
+    };
+
+    const unsigned char *chip_pl = p.swap ? p.p1 : p.p0;
+    const unsigned char *win_pl = p.swap ? p.p0 : p.p1;
+    const int Wp = p.Wp, PAD = p.pad;
+
+    // ---- point header (as match_px_kernel.hip) ---------------------------------------------------------------------
+    const double *row = p.xyuvav + (size_t)p.xy_stride * (size_t)gidx + p.xy_col;
+    const int u0 = (int)row[0], v0 = (int)row[1];
+    const int64_t pbeg = p.piv_off[gidx];
+    const int npiv = (int)(p.piv_off[gidx + 1] - pbeg);
+    const int32_t *pv_g = p.piv_uv + 2 * pbeg;
+    const int lu = pv_g[2 * (npiv - 1)], lv = pv_g[2 * (npiv - 1) + 1];
+    const int dx2 = (lu < 0 ? -lu : lu) + OCW + 2, dy2 = (lv < 0 ? -lv : lv) + OCW + 2;
+    const int Dx2 = 2 * dx2 + 1, Dy2 = 2 * dy2 + 1;
+    const int csx = Dx2 - 2 * OCW + 1, csy = Dy2 - 2 * OCW + 1;          // compact cells; a climb touches [1, cs - 2]
+    const int wu0 = u0 + p.off_u - dx2 + PAD, wv0 = v0 + p.off_v - dy2 + PAD;   // plane position of window pixel (0, 0)
+    const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;                       // ... of chip pixel (0, 0)
+    typedef unsigned long long SatT;
+    const SatT *sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
+    const SatT *sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
+    // table queries: the chip's sums and null count, the null count of the window's written area (:869-886), and -- for the
+    // closed-form T4 terms of the clean form -- the chip's last column and last row
+    const SatT chipQ = sat_box(sat_chip, p.sat_ws, cu0, cv0, CW, CW);
+    const SatT winQ = sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2);
+    SatT colQ = 0, rowQ = 0;
+    uint32_t corner = 0;
+    if (!NULLS) {
+        colQ = sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW);
+        rowQ = sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1);
+        corner = chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1];
+    }
+    // lane k = pivot k
+    int su = 0, sv = 0;
+    if (lane < npiv && npiv <= 64) { su = pv_g[2 * lane] + dx2; sv = pv_g[2 * lane + 1] + dy2; }
+
+    // ---- what this kernel takes -----------------------------------------------------------------------------------
+    // The packed table fields are exact for boxes of at most 8,224 pixels (sum b < 2^21): larger written areas go on.
+    const bool area_ok = (2 * dx2) * (2 * dy2) <= 8224;
+    // the tile: all reachable cells if they fit, else centred on the pivots' starts (a scan that leaves it hands the point on)
+    int tx0 = 1, ty0 = 1;
+    bool fits = true;
+    {
+        const int c0x = dx2 - OCW, c1x = c0x + lu, c0y = dy2 - OCW, c1y = c0y + lv;
+        const int lox = min(c0x, c1x), hix = max(c0x, c1x), loy = min(c0y, c1y), hiy = max(c0y, c1y);
+        if (csx - 2 > 32) { tx0 = min(max((lox + hix) / 2 - 15, 1), csx - 2 - 31); fits = fits && lox - 1 >= tx0 && hix + 1 <= tx0 + 31; }
+        if (csy - 2 > 32) { ty0 = min(max((loy + hiy) / 2 - 15, 1), csy - 2 - 31); fits = fits && loy - 1 >= ty0 && hiy + 1 <= ty0 + 31; }
+    }
+    const int chip_nulls = (int)(chipQ >> kSatNullShift8), win_nulls = (int)(winQ >> kSatNullShift8);
+    if (npiv > 64 || !area_ok || !fits || chip_nulls != 0) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
+    if (!NULLS && win_nulls != 0) { hand_on(p.mx_null_list, p.mx_null_count); return; }
+
+    // ---- validity (a6, :605-644): nulls of the chip / of the whole Dy2 x Dx2 search area (its last row and column are never written: zeros)
+    {
+        const float max_ratio = 0.8f;
+        const float rc = (float)chip_nulls / (float)NPX;
+        const float rw = (float)(win_nulls + Dx2 + Dy2 - 1) / (float)(Dx2 * Dy2);
+        if (rc > max_ratio || rw > max_ratio) {
+            if (lane == 0) {
+                const float nanv = __builtin_nanf("");
+                p.out[3 * (size_t)gidx + 0] = nanv; p.out[3 * (size_t)gidx + 1] = nanv; p.out[3 * (size_t)gidx + 2] = -3.0f;
+            }
+            return;
+        }
+    }
+    const uint32_t SX = (uint32_t)chipQ & ((1u << kSatSqShift8) - 1u);
+    const uint32_t SXX = (uint32_t)(chipQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+
+    // ---- stage the tile: window pixels (tx0 + x, ty0 + y), x < TW, y < TH, as signed bytes b - 128 ----------------------
+    {
+        const int gu = wu0 + tx0, gv = wv0 + ty0;
+        const int sh = gu & 3;
+        const uint32_t *gb = reinterpret_cast<const uint32_t *>(win_pl + (size_t)gv * Wp + (gu - sh));
+        const int gp = Wp >> 2;
+        constexpr int NSEG = C::TW / 16, NTASK = C::KW * NSEG;       // rows >= KW are never weighted: left as they are
+        constexpr int NIT = (NTASK + 63) / 64;
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += 4) {
+            uint32_t d[4][5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = lane + 64 * (it0 + k);
+                const int y = t / NSEG, q = t - NSEG * y;
+                const bool on = (it0 + k < NIT) && t < NTASK;
+                const uint32_t *g = gb + (size_t)(on ? y : 0) * gp + 4 * (on ? q : 0);
+#pragma unroll
+                for (int j = 0; j < 5; j++) d[k][j] = g[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = lane + 64 * (it0 + k);
+                const int y = t / NSEG, q = t - NSEG * y;
+                if ((it0 + k < NIT) && t < NTASK) {
+                    uint4 w;
+                    w.x = alignb(d[k][1], d[k][0], sh) ^ 0x80808080u;
+                    w.y = alignb(d[k][2], d[k][1], sh) ^ 0x80808080u;
+                    w.z = alignb(d[k][3], d[k][2], sh) ^ 0x80808080u;
+                    w.w = alignb(d[k][4], d[k][3], sh) ^ 0x80808080u;
+                    *reinterpret_cast<uint4 *>(WT + y * PW + 16 * q) = w;
+                }
+            }
+        }
+        // T4: the search area's last column and last row are never written (:869-886): nulls.  (What lies beyond them inside the tile
+        // only reaches cells no climb can touch.)
+        const int zx = Dx2 - 1 - tx0, zy = Dy2 - 1 - ty0;
+        if (zx < C::TW) for (int y = lane; y < C::KW; y += 64) WT[y * PW + zx] = 0x80;
+        if (zy < C::KW) for (int x = lane; x < C::TW / 4; x += 64) *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
+    }
+    // ---- chip planes: zeros, then CW rows of (a ^ 0x80) [and of the two byte planes of a^2] -------------------------------
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < (C::NPL * C::CHB) / 16; i += 64) reinterpret_cast<uint4 *>(CH)[i] = z4;
+        const int sh = cu0 & 3;
+        const uint32_t *gb = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 - sh));
+        const int gp = Wp >> 2;
+        constexpr int CD = C::CD, NTASK = CW * CD, NIT = (NTASK + 63) / 64;
+        constexpr uint32_t LASTM = C::LASTN >= 4 ? 0xffffffffu : ((1u << (8 * C::LASTN)) - 1u);
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += 5) {
+            uint32_t lo[5], hi[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int t = lane + 64 * (it0 + k);
+                const int r = t / CD, j = t - CD * r;
+                const bool on = (it0 + k < NIT) && t < NTASK;
+                const uint32_t *g = gb + (size_t)(on ? r : 0) * gp + (on ? j : 0);
+                lo[k] = g[0]; hi[k] = g[1];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int t = lane + 64 * (it0 + k);
+                const int r = t / CD, j = t - CD * r;
+                if ((it0 + k < NIT) && t < NTASK) {
+                    const uint32_t a = alignb(hi[k], lo[k], sh);
+                    const uint32_t m = (j == CD - 1) ? LASTM : 0xffffffffu;
+                    *reinterpret_cast<uint32_t *>(CH + CH0 + CP * r + 4 * j) = (a ^ 0x80808080u) & m;
+                    if (NULLS) {
+                        const uint32_t s0 = (a & 0xffu) * (a & 0xffu), s1 = ((a >> 8) & 0xffu) * ((a >> 8) & 0xffu);
+                        const uint32_t s2 = ((a >> 16) & 0xffu) * ((a >> 16) & 0xffu), s3 = (a >> 24) * (a >> 24);
+                        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);
+                        *reinterpret_cast<uint32_t *>(CH + C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x05040100u) ^ 0x80808080u) & m;
+                        *reinterpret_cast<uint32_t *>(CH + 2 * C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x07060302u) ^ 0x80808080u) & m;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    MIMC3_MX_STAMP(0)
+
+    // lane (n, h): cell column n; byte i of K chunk c <-> window column 16 KC h + 16 c + i (a lane's chunks are contiguous)
+    const int n = lane & 31, h = lane >> 5;
+    const unsigned char *arow = WT + n * PW + 16 * KC * h;
+    const int boff = CH0 + 16 * KC * h - n;
+    const uint32_t bsh = (uint32_t)boff & 3u;
+    const unsigned char *brow = CH + (boff & ~3);
+    auto load_a = [&](int r, v4i (&a)[KC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < KC; c++) a[c] = *reinterpret_cast<const v4i *>(arow + r * PW + 16 * c);
+    };
+    auto load_b = [&](int plane, int r, v4i (&b)[KC]) __attribute__((always_inline)) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + plane * C::CHB + CP * r);
+        uint32_t d[C::ND];
+#pragma unroll
+        for (int k = 0; k < C::ND; k++) d[k] = q[k];
+#pragma unroll
+        for (int c = 0; c < KC; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[4 * c + k + 1], d[4 * c + k], bsh);
+    };
+
+    // ---- window-side box sums of every cell: sum b, sum b^2 (and the null count) -------------------------------------------
+    //      row-box sums R[y][s] = sum_{x = s}^{s + CW - 1} q[y][x] by MFMA (A = the tile's rows, B = the band of ones), then
+    //      Box[dy][s] = sum_{y = dy}^{dy + CW - 1} R[y][s] by MFMA (A = the band of ones, B = the byte planes of R: the
+    //      accumulator layout has R's rows where a B operand has its K index)
+    v16i boxb, boxq, boxz = {0};
+    {
+        const Bands<CW, KC> &bd = kBands<CW, KC>;
+        v4i hb[KC];
+#pragma unroll
+        for (int c = 0; c < KC; c++) hb[c] = *reinterpret_cast<const v4i *>(&bd.hb[c][lane][0]);
+        {   // sum b (and the null count)
+            v16i v0 = {0}, v1 = {0};
+#pragma unroll
+            for (int t = 0; t < KC; t++) {
+                const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[t][lane][0]);
+                v4i a[KC];
+                load_a(32 * t, a);
+                v16i R = {0};
+#pragma unroll
+                for (int c = 0; c < KC; c++) R = mfma(a[c], hb[c], R);
+#pragma unroll
+                for (int i = 0; i < 16; i++) R[i] += 128 * CW;
+                v4i p0, p1;
+                planes2(R, p0, p1);
+                v0 = mfma(vb, p0, v0); v1 = mfma(vb, p1, v1);
+                if (NULLS) {
+                    v16i Z = {0};
+#pragma unroll
+                    for (int c = 0; c < KC; c++) Z = mfma(nullbytes(a[c]), hb[c], Z);
+                    v4i pz;
+                    planes1(Z, pz);
+                    boxz = mfma(vb, pz, boxz);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) boxb[i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW);
+        }
+        {   // sum b^2
+            v16i v0 = {0}, v1 = {0}, v2 = {0};
+#pragma unroll
+            for (int t = 0; t < KC; t++) {
+                const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[t][lane][0]);
+                v4i a[KC];
+                load_a(32 * t, a);
+                v16i Rl = {0}, Rh = {0};
+#pragma unroll
+                for (int c = 0; c < KC; c++) {
+                    v4i lo, hi;
+                    squares(a[c], lo, hi);
+                    Rl = mfma(lo, hb[c], Rl); Rh = mfma(hi, hb[c], Rh);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) Rl[i] = (Rl[i] + 128 * CW) + 256 * (Rh[i] + 128 * CW);
+                v4i p0, p1, p2;
+                planes3(Rl, p0, p1, p2);
+                v0 = mfma(vb, p0, v0); v1 = mfma(vb, p1, v1); v2 = mfma(vb, p2, v2);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) boxq[i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW) + 65536 * (v2[i] + 128 * CW);
+        }
+    }
+    MIMC3_MX_STAMP(1)
+
+    // ---- the product surface (and the null corrections) ------------------------------------------------------------------
+    v16i acc = {0}, accz = {0}, accl = {0}, acch = {0};
+    (void)accz; (void)accl; (void)acch;
+#pragma unroll 2
+    for (int r = 0; r < CW; r++) {
+        v4i a[KC], b[KC];
+        load_a(r, a);
+        load_b(0, r, b);
+#pragma unroll
+        for (int c = 0; c < KC; c++) acc = mfma(a[c], b[c], acc);
+        if (NULLS) {
+            v4i z[KC];
+#pragma unroll
+            for (int c = 0; c < KC; c++) { z[c] = nullbytes(a[c]); accz = mfma(z[c], b[c], accz); }
+            load_b(1, r, b);
+#pragma unroll
+            for (int c = 0; c < KC; c++) accl = mfma(z[c], b[c], accl);
+            load_b(2, r, b);
+#pragma unroll
+            for (int c = 0; c < KC; c++) acch = mfma(z[c], b[c], acch);
+        }
+    }
+    MIMC3_MX_STAMP(2)
+    __syncthreads();                                        // the tile's bytes become the NCC surface
+
+    // ---- NCC of the 16 cells of this lane (:734): exact integer sums, f64 formula ---------------------------------------------
+    {
+        const int cx = tx0 + n;
+        // clean form, T4 in closed form: a cell whose box reaches the never-written last column (row) loses the chip's last column (row)
+        const uint32_t cS = (uint32_t)colQ & ((1u << kSatSqShift8) - 1u), cSS = (uint32_t)(colQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+        const uint32_t rS = (uint32_t)rowQ & ((1u << kSatSqShift8) - 1u), rSS = (uint32_t)(rowQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+        const bool colT4 = cx == csx - 2;
+        const double dN = (double)NPX, dSX = (double)SX, dSXX = (double)SXX;
+        const double va0 = dN * dSXX - dSX * dSX;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ry = 8 * (i >> 2) + 4 * h + (i & 3), cy = ty0 + ry;
+            const int sy = boxb[i], syy = boxq[i];
+            const int sxy = acc[i] + 128 * ((int)SX + sy) - 16384 * NPX;
+            double dn = dN, dsx = dSX, va = va0;
+            if (NULLS) {
+                const int nz = boxz[i];
+                const int ca = accz[i] + 128 * nz, caa = (accl[i] + 128 * nz) + 256 * (acch[i] + 128 * nz);
+                dn = (double)(NPX - nz); dsx = (double)((int)SX - ca);
+                va = dn * (double)((int)SXX - caa) - dsx * dsx;
+            } else {
+                const bool rowT4 = cy == csy - 2;
+                if (colT4 || rowT4) {
+                    const int nn = NPX - (colT4 ? CW : 0) - (rowT4 ? CW : 0) + ((colT4 && rowT4) ? 1 : 0);
+                    const int sx = (int)SX - (colT4 ? (int)cS : 0) - (rowT4 ? (int)rS : 0) + ((colT4 && rowT4) ? (int)corner : 0);
+                    const int sxx = (int)SXX - (colT4 ? (int)cSS : 0) - (rowT4 ? (int)rSS : 0) + ((colT4 && rowT4) ? (int)(corner * corner) : 0);
+                    dn = (double)nn; dsx = (double)sx;
+                    va = dn * (double)sxx - dsx * dsx;
+                }
+            }
+            const double dsy = (double)sy;
+            const double num = dn * (double)sxy - dsx * dsy;
+            const double den = sqrt(va * (dn * (double)syy - dsy * dsy));
+            val[ry * VP + n] = (float)(num / den);
+        }
+    }
+    __syncthreads();
+    MIMC3_MX_STAMP(3)
+
+    // ---- the climbs (lane k = pivot k) on the complete surface; trajectories as 4-bit codes per scan -------------------------
+    auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
+        return !(pu - OCW <= 1 || pu + OCW >= Dx2 - 1 || pvv - OCW <= 1 || pvv + OCW >= Dy2 - 1);
+    };
+    // tile-relative cell of a scan centre
+    auto relx = [&](int pu) __attribute__((always_inline)) -> int { return pu - OCW - tx0; };
+    auto rely = [&](int pvv) __attribute__((always_inline)) -> int { return pvv - OCW - ty0; };
+    constexpr int kSpecRounds = 16;
+    const int start_u = su, start_v = sv;
+    bool alive = lane < npiv && inside(su, sv);
+    bool left = false;                                       // a scan would leave the tile
+    unsigned long long traj = 0ull;                          // 0 = no scan, 1..9 = the scan updated the maximum at 3x3 index code-1 (5 = centre), 10 = no update
+    int nsc = 0;
+    {
+        float smax = -2.0f;
+        while (alive && nsc < kSpecRounds) {
+            const int rx = relx(su), ry = rely(sv);
+            if (rx < 1 || rx > 30 || ry < 1 || ry > 30) { left = true; break; }
+            float v[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) v[j] = val[(ry + (j % 3 - 1)) * VP + rx + (j / 3 - 1)];
+            const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]), __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5])),
+                                            __builtin_fmaxf(__builtin_fmaxf(v[6], v[7]), v[8]));
+            int mv = -1;
+            if (m > smax) {
+                mv = 8;
+#pragma unroll
+                for (int j = 7; j >= 0; j--) mv = (v[j] == m) ? j : mv;
+                smax = m;
+            }
+            const bool moved = (mv >= 0 && mv != 4);
+            if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; }
+            traj |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * nsc);
+            nsc++;
+            alive = moved && inside(su, sv);
+        }
+    }
+    if (__any(left)) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
+    MIMC3_MX_STAMP(4)
+
+    // ---- exact replay: the visited state only decides HOW MANY scans of a pivot really happen (newncc != 0, :699) -- sequential over
+    //      pivots; lane r holds the visited bits of tile row r (match_px_kernel.hip, "exact replay", with 32-bit rows)
+    int T = 0;
+    uint32_t vrow = 0u;
+    {
+        uint32_t dlo = 0u, dhi = 0u;                          // this lane's moves, 4 bits per scan: (du + 1) | (dv + 1) << 2; 5 = no move
+#pragma unroll
+        for (int t = 0; t < kSpecRounds; t++) {
+            if (__ballot(nsc > t) == 0ull) break;
+            const uint32_t code = (uint32_t)(traj >> (4 * t)) & 15u;
+            const bool moved = (code - 1u) < 9u && code != 5u;
+            const uint32_t mv = code - 1u, q3 = (mv * 11u) >> 5;
+            const uint32_t d = moved ? (q3 | ((mv - 3u * q3) << 2)) : 5u;
+            if (t < 8) dlo |= d << (4 * (t & 7)); else dhi |= d << (4 * (t & 7));
+        }
+        const uint32_t head = (uint32_t)(relx(start_u) & 0xff) | ((uint32_t)(rely(start_v) & 0xff) << 8) | ((uint32_t)nsc << 16);
+        for (int kk = 0; kk < npiv; kk++) {
+            const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)head, kk);
+            const int n_k = (int)(hd >> 16);
+            int ccx = (int)(hd & 0xffu), cy1 = (int)((hd >> 8) & 0xffu) - 1;      // centre column, centre row - 1 (tile-relative)
+            unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, kk) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)dlo, kk);
+            int t = 0;
+            while (t < n_k) {
+                // rows cy1 .. cy1 + 2 (= lanes) test and set their three bits; fresh3 = the lanes that held an unvisited one
+                unsigned long long fresh3, sv2;
+                uint32_t tmp;
+                const uint32_t m3 = 7u << (ccx - 1);
+                asm volatile("v_subrev_u32_e32 %[tmp], %[y], %[l1]\n\t"
+                             "v_cmp_gt_u32_e32 vcc, 3, %[tmp]\n\t"
+                             "s_and_saveexec_b64 %[sv], vcc\n\t"
+                             "v_bitop3_b32 %[tmp], %[m], %[v], %[m] bitop3:0x30\n\t"      // m3 & ~vrow
+                             "v_cmp_ne_u32_e32 vcc, 0, %[tmp]\n\t"
+                             "v_or_b32_e32 %[v], %[m], %[v]\n\t"
+                             "s_mov_b64 exec, %[sv]\n\t"
+                             "s_mov_b64 %[fr], vcc"
+                             : [tmp] "=&v"(tmp), [sv] "=&s"(sv2), [fr] "=s"(fresh3), [v] "+v"(vrow)
+                             : [y] "s"(cy1), [l1] "v"(lane), [m] "s"(m3)
+                             : "vcc", "scc");
+                t++;
+                const uint32_t d = (uint32_t)cur & 15u;
+                cur >>= 4;
+                ccx += (int)(d & 3u) - 1; cy1 += (int)(d >> 2) - 1;
+                if (fresh3 == 0ull) break;
+                if (d == 5u) break;
+            }
+            T = (lane == kk) ? t : T;
+        }
+    }
+    // a pivot whose speculation was cut at 16 scans and whose real climb consumed all of them: the register-tiled kernel decides
+    if (__any(alive && T == nsc)) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
+    if (lane < 32) vis[lane] = vrow;
+    MIMC3_MX_STAMP(5)
+
+    // ---- best of pivots (:744-752): after its last updating scan a pivot sits on the arg-max cell
+    int peak_u = dx2, peak_v = dy2;
+    float best = -2.0f;
+    {
+        int fu = start_u, fv = start_v;
+        bool upd = false;
+        for (int t = 0; t < T; t++) {
+            const int code = (int)((traj >> (4 * t)) & 15ull);
+            if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
+        }
+        const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
+        const float fmax = upd ? val[rely(fv) * VP + relx(fu)] : -2.0f;
+        float bv = (lane < npiv) ? fmax : -__builtin_inff();
+        int bi = lane;
+        argmax_row16(bv, bi);
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        bv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
+        bi = __builtin_amdgcn_readfirstlane(bi);
+        if (bv > -2.0f) {                                    // strict >, first pivot attaining the maximum wins
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)fpos, bi & 63);
+            peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
+        }
+    }
+    __syncthreads();
+    // ---- 3x3 quadratic fit (:757-788), the reference's arithmetic value by value (match_px_kernel.hip) ------------------------------
+    if (lane < 5) {
+        float n9[9];
+        const int px = relx(peak_u), py = rely(peak_v);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int x = px - 1 + c, y = py - 1 + r;
+                const bool in = (unsigned)x < 32u && (unsigned)y < 32u;                          // (a cell outside the tile was never scanned)
+                n9[3 * r + c] = (in && ((vis[in ? y : 0] >> (x & 31)) & 1u)) ? val[y * VP + x] : -2.0f;
+            }
+        const float e0 = 6 * n9[0] - 12 * n9[1] + 6 * n9[2] + 6 * n9[3] - 12 * n9[4] + 6 * n9[5] + 6 * n9[6] - 12 * n9[7] + 6 * n9[8];
+        const float e1 = 9 * n9[0] - 9 * n9[2] - 9 * n9[6] + 9 * n9[8];
+        const float e2 = 6 * n9[0] + 6 * n9[1] + 6 * n9[2] - 12 * n9[3] - 12 * n9[4] - 12 * n9[5] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+        const float e3 = -6 * n9[0] + 6 * n9[2] - 6 * n9[3] + 6 * n9[5] - 6 * n9[6] + 6 * n9[8];
+        const float e4 = -6 * n9[0] - 6 * n9[1] - 6 * n9[2] + 6 * n9[6] + 6 * n9[7] + 6 * n9[8];
+        double cp = (double)(lane == 0 ? e0 : (lane == 1 ? e1 : (lane == 2 ? e2 : (lane == 3 ? e3 : e4))));
+        cp /= 36;
+        auto from_lane = [&](int ln) __attribute__((always_inline)) -> double {
+            const long long bits = __double_as_longlong(cp);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, ln), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), ln);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        const double cp0 = from_lane(0), cp1 = from_lane(1), cp2 = from_lane(2), cp3 = from_lane(3), cp4 = from_lane(4);
+        const float num = lane == 0 ? (float)(-2 * cp2 * cp3 + cp1 * cp4) : (float)(-2 * cp0 * cp4 + cp1 * cp3);
+        const double det = 4 * cp0 * cp2 - cp1 * cp1;
+        float o = (float)((double)num / det);
+        o += (float)(lane == 0 ? peak_u - dx2 : peak_v - dy2);
+        if (lane < 2) p.out[3 * (size_t)gidx + lane] = o;
+        if (lane == 0) p.out[3 * (size_t)gidx + 2] = best;
+    }
+    MIMC3_MX_STAMP(6)
+}
+
+template <class C>
+static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
+{
+    const unsigned nb = (unsigned)((a.N + 7) & ~7);
+    static unsigned long long *d_stats = nullptr;
+    static const bool want_stats = getenv("MIMC3_MX_STATS") != nullptr;
+    static size_t stats_n = 0;
+    static std::mutex stats_mu;                      // diagnostics only
+    std::unique_lock<std::mutex> stats_lock(stats_mu, std::defer_lock);
+    if (want_stats) {
+        stats_lock.lock();
+        if (stats_n < (size_t)nb) {
+            if (d_stats) (void)hipFree(d_stats);
+            (void)hipMalloc(&d_stats, kStatW * sizeof(unsigned long long) * (size_t)nb);
+            stats_n = nb;
+        }
+        (void)hipMemsetAsync(d_stats, 0, kStatW * sizeof(unsigned long long) * (size_t)nb, stream);
+    }
+    a.stats = want_stats ? d_stats : nullptr;
+    hipLaunchKernelGGL(match_ncc_dlc_mx<C>, dim3(nb), dim3(64), 0, stream, a);
+    if (want_stats) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long *hh = (unsigned long long *)malloc(kStatW * sizeof(unsigned long long) * (size_t)nb);
+        (void)hipMemcpy(hh, d_stats, kStatW * sizeof(unsigned long long) * (size_t)nb, hipMemcpyDeviceToHost);
+        unsigned long long hsum[kStatW] = {0};
+        size_t live = 0;
+        for (size_t b = 0; b < (size_t)nb; b++) { if (hh[kStatW * b]) live++; for (int i = 0; i < kStatW; i++) hsum[i] += hh[kStatW * b + i]; }
+        free(hh);
+        const double d = live ? (double)live : 1.0;
+        int32_t nn = 0, nr = 0;
+        if (a.mx_null_count) (void)hipMemcpy(&nn, a.mx_null_count, sizeof(nn), hipMemcpyDeviceToHost);
+        if (a.mx_rest_count) (void)hipMemcpy(&nr, a.mx_rest_count, sizeof(nr), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f box sums %.0f products %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
+                C::OCW, C::NULLS ? "nulls" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mx
+
+bool match_mx_supported(int ocw, int max_npiv, int win_half)
+{
+    static const int off = getenv("MIMC3_MX") ? atoi(getenv("MIMC3_MX")) : 1;      // tuning / A-B: 0 = never take this kernel
+    if (!off) return false;
+    if (win_half > 0) return false;                   // full-square search areas (control-point stage): many pivots, not this kernel
+    (void)max_npiv;
+    return ocw == 16;
+}
+
+// Two launches: the clean form over all points (or the caller's list), the NULLS form over the points it handed on.  Points neither
+// takes are in mx_rest_list afterwards.
+hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
+{
+    if (a.N <= 0) return hipSuccess;
+    if (!a.mx_null_list || !a.mx_null_count || !a.mx_rest_list || !a.mx_rest_count || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    switch (a.ocw) {
+    case 16: e = mx::launch_one<mx::Cfg<16, false>>(a, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    a.point_list = a.mx_null_list; a.point_count = a.mx_null_count;
+    switch (a.ocw) {
+    case 16: e = mx::launch_one<mx::Cfg<16, true>>(a, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return e;
+}
+
+}  // namespace mimc3
