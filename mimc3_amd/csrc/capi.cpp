@@ -116,7 +116,7 @@ struct mimc3_ctx {
     bool no_u8o = false;                // internal (CP stage): never try the per-point-offset u8 form on this context's pairs
     int32_t lane = 0;                   // internal (CP stage): which scratch set (overflow lists) the next matcher call uses: calls on
     DevBuf ovf_alt[3], fail_alt[3];     // different streams of one context must not share them
-    DevBuf mxl[4];                      // matrix-core kernel: [0] null-list count, [1] rest-list count, then the two lists (one set per `lane`)
+    DevBuf mxl[4];                      // matrix-core kernel: one flag byte per grid point (one buffer per `lane`)
     int32_t win_half = 0;               // internal (CP stage): > 0 = the next matcher calls use a full (2*win_half+1)^2 search area
     mimc3_ctx *cp_child[4] = {nullptr, nullptr, nullptr, nullptr};   // CP stage: one context per image variant for its chip atlas (planes, kernel selection)
     DevBuf cellws;                      // general matcher: global cell-grid workspace for corridors whose cell grid outgrows LDS
@@ -631,13 +631,12 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
                 // dense correlation surfaces on the matrix cores first; the points that kernel does not take (chips with nulls,
                 // corridors wider than its tile, ...) are redone by the register-tiled kernel in list mode, no host round trip
                 DevBuf &ml = c->mxl[c->lane];
-                HIP_TRY(ml.reserve(sizeof(int32_t) * (2 * (size_t)N + 2)));
-                HIP_TRY(hipMemsetAsync(ml.p, 0, 2 * sizeof(int32_t), s));
-                u.mx_null_count = static_cast<int32_t *>(ml.p); u.mx_rest_count = u.mx_null_count + 1;
-                u.mx_null_list = u.mx_null_count + 2; u.mx_rest_list = u.mx_null_list + N;
+                HIP_TRY(ml.reserve((size_t)N));
+                HIP_TRY(hipMemsetAsync(ml.p, 0, (size_t)N, s));
+                u.mx_flags = static_cast<uint8_t *>(ml.p);
                 e = mimc3::launch_match_mx(u, s);
                 if (e == hipSuccess) {
-                    u.point_count = u.mx_rest_count; u.point_list = u.mx_rest_list;
+                    u.point_flags = u.mx_flags; u.flag_value = mimc3::kMxRest;
                     e = mimc3::launch_match_u8(u, max_abs_piv_u, max_abs_piv_v, max_npiv, s);
                 }
                 c->last_path = 5;

@@ -35,6 +35,7 @@ constexpr int kCellGlobalGrid = 1024;   // persistent workgroups of the workspac
 size_t match_f32_workspace_bytes(int ocw, int max_abs_u, int max_abs_v, int max_npiv, int win_half);
 
 // ---- exact-integer path for 8-bit imagery (match_u8_kernel.hip) -------------------------------
+constexpr uint8_t kMxNulls = 2, kMxRest = 1;
 constexpr int kU8Pad = 256;      // zero border (pixels) around the u8 planes; multiple of 4
 
 struct MatchU8Args {                // arguments of the register-tiled kernel family (match_px_kernel.hip)
@@ -55,8 +56,13 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     int32_t *ovf_list, *ovf_count;  // points whose NCC cache overflowed: handed to the general kernel (list mode)
     const int32_t *point_list, *point_count;   // list mode: workgroup b handles point_list[b], b < *point_count (nullptr = all N points)
     int32_t *fail_list, *fail_count;           // PxU8o only: points whose chip or window does not fit a local 8-bit range
-    // matrix-core kernel (match_mx_kernel.hip): points its clean form hands to its window-null form / points neither form takes
-    int32_t *mx_null_list, *mx_null_count, *mx_rest_list, *mx_rest_count;
+    // matrix-core kernel (match_mx_kernel.hip): one byte per grid point, zero before the first launch -- kMxNulls = handed from its clean
+    // form to its window-null form, kMxRest = neither form takes the point (plain stores: a shared list counter serialises ~100,000
+    // same-address atomics per launch, measured 1.0 ms)
+    uint8_t *mx_flags;
+    // flag mode of every kernel of the family: workgroup b handles point b only if point_flags[b] == flag_value
+    const uint8_t *point_flags;
+    int32_t flag_value;
     // LDS carve, filled by the launcher
     int32_t lds_pw, lds_off_val, lds_off_vis, lds_off_list, lds_off_sums, lds_off_piv, lds_list_cap;
     int32_t lds_off_chip, lds_off_lw, lds_off_lc;   // big-chip integer configs: LDS chip copy, window-null and chip-null lists

@@ -71,7 +71,8 @@ struct Cfg {
     static constexpr int LASTN = CW - 4 * (CD - 1);  // valid bytes of a chip row's last dword
     static constexpr int CP = (CW + 31 > TW ? ((CW + 31 + 3) & ~3) : TW);   // chip plane pitch: a row's right padding is the next row's left padding
     static constexpr int CH0 = 32;                   // leading zeros (row 0's left padding)
-    static constexpr int CHB = (CH0 + CW * CP + 16 + 15) & ~15;             // one chip plane (+ the read-ahead of the last row's last lane)
+    static constexpr int CWE = CW + (CW & 1);       // chip rows the product loop walks: two per trip (an all-zero row behind an odd chip)
+    static constexpr int CHB = (CH0 + CWE * CP + 16 + 15) & ~15;            // one chip plane (+ the read-ahead of the last row's last lane)
     static constexpr int NPL = NULLS_ ? 3 : 1;       // chip planes: a', and for the null corrections (a^2 & 255)', (a^2 >> 8)'
     static constexpr int ND = 4 * KC + 1;            // dwords a lane reads for one chip row (its 16 KC bytes at a byte phase)
     static constexpr int VP = 33;                    // pitch (words) of the NCC surface
@@ -168,12 +169,15 @@ __device__ __forceinline__ void planes1(const v16i &R, v4i &p0)
     }
 }
 
+// diagnostics (MIMC3_MX_STATS): phase clocks stay in scalar registers and are stored once, by MIMC3_MX_STATS_OUT, before the kernel's normal exit
 #define MIMC3_MX_STAMP(i)                                                                      \
     if (p.stats) {                                                                             \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
-        if (lane == 0) p.stats[kStatW * (size_t)blockIdx.x + i] += t_now - t_prev;             \
+        t_ph[i] = t_now - t_prev;                                                              \
         t_prev = t_now;                                                                        \
     }
+#define MIMC3_MX_STATS_OUT                                                                     \
+    if (p.stats && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 7; i_++) p.stats[kStatW * (size_t)blockIdx.x + i_] = t_ph[i_]; }
 
 template <class C>
 __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     unsigned char *CH = smem + C::OFF_CH;                               // chip planes
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + C::OFF_VIS);    // visited bits of the 32 tile rows
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0};
     const int lane = threadIdx.x;
 
     int gidx = blockIdx.x;
@@ -197,8 +202,9 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);   // XCD-contiguous point order
     }
     if (gidx >= p.N) return;
-    auto hand_on = [&](int32_t *list, int32_t *count) __attribute__((always_inline)) {
-        if (lane == 0) list[atomicAdd(count, 1)] = gidx;
+    if (p.point_flags && p.point_flags[gidx] != (uint8_t)p.flag_value) return;      // flag mode: the points another kernel handed over
+    auto hand_on = [&](uint8_t to) __attribute__((always_inline)) {
+        if (lane == 0) p.mx_flags[gidx] = to;
     };
 
     const unsigned char *chip_pl = p.swap ? p.p1 : p.p0;
@@ -248,8 +254,8 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         if (csy - 2 > 32) { ty0 = min(max((loy + hiy) / 2 - 15, 1), csy - 2 - 31); fits = fits && loy - 1 >= ty0 && hiy + 1 <= ty0 + 31; }
     }
     const int chip_nulls = (int)(chipQ >> kSatNullShift8), win_nulls = (int)(winQ >> kSatNullShift8);
-    if (npiv > 64 || !area_ok || !fits || chip_nulls != 0) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
-    if (!NULLS && win_nulls != 0) { hand_on(p.mx_null_list, p.mx_null_count); return; }
+    if (npiv > 64 || !area_ok || !fits || chip_nulls != 0) { hand_on(kMxRest); return; }
+    if (!NULLS && win_nulls != 0) { hand_on(kMxNulls); return; }
 
     // ---- validity (a6, :605-644): nulls of the chip / of the whole Dy2 x Dx2 search area (its last row and column are never written: zeros)
     {
@@ -359,16 +365,6 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
 #pragma unroll
         for (int c = 0; c < KC; c++) a[c] = *reinterpret_cast<const v4i *>(arow + r * PW + 16 * c);
     };
-    auto load_b = [&](int plane, int r, v4i (&b)[KC]) __attribute__((always_inline)) {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + plane * C::CHB + CP * r);
-        uint32_t d[C::ND];
-#pragma unroll
-        for (int k = 0; k < C::ND; k++) d[k] = q[k];
-#pragma unroll
-        for (int c = 0; c < KC; c++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[4 * c + k + 1], d[4 * c + k], bsh);
-    };
 
     // ---- window-side box sums of every cell: sum b, sum b^2 (and the null count) -------------------------------------------
     //      row-box sums R[y][s] = sum_{x = s}^{s + CW - 1} q[y][x] by MFMA (A = the tile's rows, B = the band of ones), then
@@ -434,64 +430,130 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     MIMC3_MX_STAMP(1)
 
     // ---- the product surface (and the null corrections) ------------------------------------------------------------------
+    //      Software-pipelined by hand: the LDS reads of chip row r + 1 are in flight while row r's MFMAs issue (left to the compiler,
+    //      every row waited for its own reads: one LDS latency per row, the MFMA pipe a sixth busy).
     v16i acc = {0}, accz = {0}, accl = {0}, acch = {0};
     (void)accz; (void)accl; (void)acch;
-#pragma unroll 2
-    for (int r = 0; r < CW; r++) {
-        v4i a[KC], b[KC];
-        load_a(r, a);
-        load_b(0, r, b);
+    {
+        struct RowOps { v4i a[KC]; uint32_t d[C::NPL][C::ND]; };
+        auto issue = [&](int r, RowOps &o) __attribute__((always_inline)) {
+            load_a(r, o.a);
 #pragma unroll
-        for (int c = 0; c < KC; c++) acc = mfma(a[c], b[c], acc);
-        if (NULLS) {
-            v4i z[KC];
+            for (int pl = 0; pl < C::NPL; pl++) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r);
 #pragma unroll
-            for (int c = 0; c < KC; c++) { z[c] = nullbytes(a[c]); accz = mfma(z[c], b[c], accz); }
-            load_b(1, r, b);
+                for (int k = 0; k < C::ND; k++) o.d[pl][k] = q[k];
+            }
+        };
+        auto shifted = [&](const uint32_t (&d)[C::ND], v4i (&b)[KC]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < KC; c++) accl = mfma(z[c], b[c], accl);
-            load_b(2, r, b);
+            for (int c = 0; c < KC; c++)
 #pragma unroll
-            for (int c = 0; c < KC; c++) acch = mfma(z[c], b[c], acch);
+                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[4 * c + k + 1], d[4 * c + k], bsh);
+        };
+        auto consume = [&](const RowOps &o) __attribute__((always_inline)) {
+            v4i b[KC];
+            shifted(o.d[0], b);
+#pragma unroll
+            for (int c = 0; c < KC; c++) acc = mfma(o.a[c], b[c], acc);
+            if constexpr (NULLS) {
+                v4i z[KC];
+#pragma unroll
+                for (int c = 0; c < KC; c++) { z[c] = nullbytes(o.a[c]); accz = mfma(z[c], b[c], accz); }
+                shifted(o.d[1], b);
+#pragma unroll
+                for (int c = 0; c < KC; c++) accl = mfma(z[c], b[c], accl);
+                shifted(o.d[2], b);
+#pragma unroll
+                for (int c = 0; c < KC; c++) acch = mfma(z[c], b[c], acch);
+            }
+        };
+        // (no branch inside the loop: with conditional reads the compiler's wait counts assume the shorter queue and every row waits for the
+        //  reads issued behind it; an odd chip is followed by an all-zero row, whose products add nothing)
+        RowOps o0, o1;
+        issue(0, o0);
+#pragma unroll 1
+        for (int r = 0; r < C::CWE; r += 2) {
+            issue(r + 1, o1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(r + 2 < C::CWE ? r + 2 : r + 1, o0);          // (the last trip re-reads a row: nothing consumes it)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(o1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     MIMC3_MX_STAMP(2)
     __syncthreads();                                        // the tile's bytes become the NCC surface
 
-    // ---- NCC of the 16 cells of this lane (:734): exact integer sums, f64 formula ---------------------------------------------
+    // ---- NCC of the 16 cells of this lane (:734): exact integer sums, the f64 formula rounded to f32 ------------------------------
+    //   reference:  (float)( num / sqrt(P) ),  num = n sxy - sx sy  and  va = n sxx - sx^2,  vb = n syy - sy^2  exact integers in f64,
+    //               P = va * vb rounded once, sqrt and the division correctly rounded: the f64 quotient Qd is within 2^-51 of num / sqrt(P).
+    //   here:       r = v_rsq_f64(P) refined by one Newton step (relative error <= 1.5 e^2 + a few 2^-53, e = the instruction's error,
+    //               2^-23 by the ISA's "2^29 ulp"), Q' = num * r'.  Q' and Qd round to the SAME f32 unless an f32 rounding boundary lies
+    //               between them: a cell whose Q' is within 2^-40 |Q'| of a boundary (or whose P is not positive: the reference's
+    //               inf / NaN cases) is redone with the reference's own operations.  2^-15 of the cells; every bit of every cell is
+    //               the reference's either way (tests/test_mx_finish.py brute-forces the guard on the device).
     {
         const int cx = tx0 + n;
         // clean form, T4 in closed form: a cell whose box reaches the never-written last column (row) loses the chip's last column (row)
         const uint32_t cS = (uint32_t)colQ & ((1u << kSatSqShift8) - 1u), cSS = (uint32_t)(colQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
         const uint32_t rS = (uint32_t)rowQ & ((1u << kSatSqShift8) - 1u), rSS = (uint32_t)(rowQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
-        const bool colT4 = cx == csx - 2;
-        const double dN = (double)NPX, dSX = (double)SX, dSXX = (double)SXX;
-        const double va0 = dN * dSXX - dSX * dSX;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int ry = 8 * (i >> 2) + 4 * h + (i & 3), cy = ty0 + ry;
-            const int sy = boxb[i], syy = boxq[i];
-            const int sxy = acc[i] + 128 * ((int)SX + sy) - 16384 * NPX;
-            double dn = dN, dsx = dSX, va = va0;
+        const bool colT4 = !NULLS && cx == csx - 2;
+        const int rT4 = NULLS ? -1 : csy - 2 - ty0;         // tile row of the cells that reach the never-written last row
+        // (n, sx, va) of this lane's cells: off / on the T4 row
+        double dn0, dsx0, va0, dn1, dsx1, va1;
+        {
+            const int n0 = NPX - (colT4 ? CW : 0), sx0 = (int)SX - (colT4 ? (int)cS : 0), sxx0 = (int)SXX - (colT4 ? (int)cSS : 0);
+            const int n1 = n0 - CW + (colT4 ? 1 : 0), sx1 = sx0 - (int)rS + (colT4 ? (int)corner : 0), sxx1 = sxx0 - (int)rSS + (colT4 ? (int)(corner * corner) : 0);
+            dn0 = (double)n0; dsx0 = (double)sx0; va0 = dn0 * (double)sxx0 - dsx0 * dsx0;
+            dn1 = (double)n1; dsx1 = (double)sx1; va1 = dn1 * (double)sxx1 - dsx1 * dsx1;
+        }
+        auto cell_in = [&](int i, double &dn, double &dsx, double &va, int &sxy, int &sy, int &syy) __attribute__((always_inline)) {
+            const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
+            sy = boxb[i]; syy = boxq[i];
+            sxy = acc[i] + 128 * ((int)SX + sy) - 16384 * NPX;
             if (NULLS) {
                 const int nz = boxz[i];
                 const int ca = accz[i] + 128 * nz, caa = (accl[i] + 128 * nz) + 256 * (acch[i] + 128 * nz);
                 dn = (double)(NPX - nz); dsx = (double)((int)SX - ca);
                 va = dn * (double)((int)SXX - caa) - dsx * dsx;
             } else {
-                const bool rowT4 = cy == csy - 2;
-                if (colT4 || rowT4) {
-                    const int nn = NPX - (colT4 ? CW : 0) - (rowT4 ? CW : 0) + ((colT4 && rowT4) ? 1 : 0);
-                    const int sx = (int)SX - (colT4 ? (int)cS : 0) - (rowT4 ? (int)rS : 0) + ((colT4 && rowT4) ? (int)corner : 0);
-                    const int sxx = (int)SXX - (colT4 ? (int)cSS : 0) - (rowT4 ? (int)rSS : 0) + ((colT4 && rowT4) ? (int)(corner * corner) : 0);
-                    dn = (double)nn; dsx = (double)sx;
-                    va = dn * (double)sxx - dsx * dsx;
-                }
+                const bool rowT4 = ry == rT4;
+                dn = rowT4 ? dn1 : dn0; dsx = rowT4 ? dsx1 : dsx0; va = rowT4 ? va1 : va0;
             }
+        };
+        uint32_t amb = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
+            double dn, dsx, va; int sxy, sy, syy;
+            cell_in(i, dn, dsx, va, sxy, sy, syy);
             const double dsy = (double)sy;
             const double num = dn * (double)sxy - dsx * dsy;
-            const double den = sqrt(va * (dn * (double)syy - dsy * dsy));
-            val[ry * VP + n] = (float)(num / den);
+            const double P = va * (dn * (double)syy - dsy * dsy);
+            const double r = __builtin_amdgcn_rsq(P);
+            const double g = P * r;
+            const double e2 = __builtin_fma(-r, g, 1.0);
+            const double r1 = __builtin_fma(0.5 * r, e2, r);
+            const double q = num * r1;
+            const uint32_t low = ((uint32_t)__double2loint(q) & 0x1fffffffu) - (0x10000000u - 0x2000u);     // distance to the f32 rounding boundary, + 2^13
+            if (!(P > 0.0) || low <= 0x4000u) amb |= 1u << i;
+            val[ry * VP + n] = (float)q;
+        }
+        if (__any(amb != 0u)) {                            // rare (2^-15 of the cells): the reference's own operations
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (!__any((amb >> i) & 1u)) continue;
+                double dn, dsx, va; int sxy, sy, syy;
+                cell_in(i, dn, dsx, va, sxy, sy, syy);
+                const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
+                const double dsy = (double)sy;
+                const double num = dn * (double)sxy - dsx * dsy;
+                const double den = sqrt(va * (dn * (double)syy - dsy * dsy));
+                if ((amb >> i) & 1u) val[ry * VP + n] = (float)(num / den);
+            }
         }
     }
     __syncthreads();
@@ -534,7 +596,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
             alive = moved && inside(su, sv);
         }
     }
-    if (__any(left)) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
+    if (__any(left)) { hand_on(kMxRest); return; }
     MIMC3_MX_STAMP(4)
 
     // ---- exact replay: the visited state only decides HOW MANY scans of a pivot really happen (newncc != 0, :699) -- sequential over
@@ -587,7 +649,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         }
     }
     // a pivot whose speculation was cut at 16 scans and whose real climb consumed all of them: the register-tiled kernel decides
-    if (__any(alive && T == nsc)) { hand_on(p.mx_rest_list, p.mx_rest_count); return; }
+    if (__any(alive && T == nsc)) { hand_on(kMxRest); return; }
     if (lane < 32) vis[lane] = vrow;
     MIMC3_MX_STAMP(5)
 
@@ -653,6 +715,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         if (lane == 0) p.out[3 * (size_t)gidx + 2] = best;
     }
     MIMC3_MX_STAMP(6)
+    MIMC3_MX_STATS_OUT
 }
 
 template <class C>
@@ -685,8 +748,12 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
         free(hh);
         const double d = live ? (double)live : 1.0;
         int32_t nn = 0, nr = 0;
-        if (a.mx_null_count) (void)hipMemcpy(&nn, a.mx_null_count, sizeof(nn), hipMemcpyDeviceToHost);
-        if (a.mx_rest_count) (void)hipMemcpy(&nr, a.mx_rest_count, sizeof(nr), hipMemcpyDeviceToHost);
+        {
+            unsigned char *hf = (unsigned char *)malloc((size_t)a.N);
+            (void)hipMemcpy(hf, a.mx_flags, (size_t)a.N, hipMemcpyDeviceToHost);
+            for (int i = 0; i < a.N; i++) { nn += hf[i] == kMxNulls; nr += hf[i] == kMxRest; }
+            free(hf);
+        }
         fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f box sums %.0f products %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
                 C::OCW, C::NULLS ? "nulls" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
     }
@@ -704,19 +771,19 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half)
     return ocw == 16;
 }
 
-// Two launches: the clean form over all points (or the caller's list), the NULLS form over the points it handed on.  Points neither
-// takes are in mx_rest_list afterwards.
+// Two launches: the clean form over all points (or the caller's list), the NULLS form over the points it flagged.  Points neither
+// takes carry kMxRest in mx_flags afterwards.
 hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
-    if (!a.mx_null_list || !a.mx_null_count || !a.mx_rest_list || !a.mx_rest_count || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
+    if (!a.mx_flags || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     switch (a.ocw) {
     case 16: e = mx::launch_one<mx::Cfg<16, false>>(a, stream); break;
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    a.point_list = a.mx_null_list; a.point_count = a.mx_null_count;
+    a.point_flags = a.mx_flags; a.flag_value = kMxNulls;
     switch (a.ocw) {
     case 16: e = mx::launch_one<mx::Cfg<16, true>>(a, stream); break;
     default: return hipErrorInvalidValue;

@@ -745,6 +745,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         if (per > 0 && gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);   // XCD-contiguous point order
     }
     if (gidx >= p.N) return;
+    if (p.point_flags && p.point_flags[gidx] != (uint8_t)p.flag_value) return;      // flag mode: the points the matrix-core kernel left
 
     const unsigned char *chip_pl = p.swap ? p.p1 : p.p0;
     const unsigned char *win_pl = p.swap ? p.p0 : p.p1;
