@@ -42,7 +42,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t alignb(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ v16i mfma(const v4i &a, const v4i &b, const v16i &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+// a wave-uniform value the compiler loaded through the vector memory path (global stores in the kernel keep it from using scalar loads): into SGPRs
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ v4i mfma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 
 // first-wins arg-max over the 16 lanes of a DPP row (lexicographic max on (value, -index)); VALU only
 __device__ __forceinline__ void argmax_row16(float &v, int &i)
@@ -62,52 +68,68 @@ template <int OCW_, bool NULLS_>
 struct Cfg {
     static constexpr int OCW = OCW_, CW = 2 * OCW_ + 1, NPX = CW * CW;
     static constexpr bool NULLS = NULLS_;
-    static constexpr int KW = CW + 31;               // window columns (and rows) the 32 x 32 cells of a tile reach
-    static constexpr int KC = (KW + 31) / 32;        // MFMAs per chip row (K chunks of 32 window columns)
-    static constexpr int TW = 32 * KC;               // staged tile: bytes per row ...
-    static constexpr int PW = TW + 16;               // ... at a pitch of 16 x odd: the 16 lanes of a ds_read_b128 group hit 16 distinct slots
-    static constexpr int TH = 32 * KC;               // rows (the row tiles of the box sums read whole 32-row tiles; rows >= KW carry weight 0)
-    static constexpr int CD = (CW + 3) / 4;          // dwords per chip row
-    static constexpr int LASTN = CW - 4 * (CD - 1);  // valid bytes of a chip row's last dword
-    static constexpr int CP = (CW + 31 > TW ? ((CW + 31 + 3) & ~3) : TW);   // chip plane pitch: a row's right padding is the next row's left padding
-    static constexpr int CH0 = 32;                   // leading zeros (row 0's left padding)
-    static constexpr int CWE = CW + (CW & 1);       // chip rows the product loop walks: two per trip (an all-zero row behind an odd chip)
-    static constexpr int CHB = (CH0 + CWE * CP + 16 + 15) & ~15;            // one chip plane (+ the read-ahead of the last row's last lane)
-    static constexpr int NPL = NULLS_ ? 3 : 1;       // chip planes: a', and for the null corrections (a^2 & 255)', (a^2 >> 8)'
-    static constexpr int ND = 4 * KC + 1;            // dwords a lane reads for one chip row (its 16 KC bytes at a byte phase)
-    static constexpr int VP = 33;                    // pitch (words) of the NCC surface
-    static constexpr int LDS_W = TH * PW;
+    // Two waves per grid point: wave w owns the cell columns [16 w, 16 w + 16) of the 32 x 32 tile (two 16 x 16 MFMA tiles, rows
+    // 0..15 and 16..31), so each wave carries half the accumulators.  The front phases run on both, the climb / replay / fit on wave 0
+    // after wave 1 has left: registers per wave, not LDS, bound how many points a CU works on.
+    static constexpr int NW = 2, NT = 64 * NW;
+    static constexpr int KW = CW + 31;                  // window columns (and rows) the 32 x 32 cells of a tile reach
+    static constexpr int KCW = (CW + 15 + 63) / 64;     // MFMAs per chip row and 16 x 16 cell tile (K chunks of 64 window columns, from column 16 w)
+    static constexpr int RDW = 16 * (NW - 1) + 64 * KCW;   // bytes of a tile row some wave reads
+    static constexpr int SW = (KW + 15) & ~15;          // bytes of a tile row that are staged (what lies beyond is only ever weighted 0)
+    static constexpr int PW0 = RDW > SW ? RDW : SW;
+    static constexpr int PW = ((PW0 / 16) & 1) ? PW0 : PW0 + 16;   // pitch 16 x odd: few bank conflicts between the rows of a ds_read_b128 group
+    static constexpr int NTR = (KW + 15) / 16;          // 16-row tiles of the row-box sums
+    static constexpr int KCV = (NTR + 3) / 4;           // K chunks (64 tile rows) of the vertical sums
+    static constexpr int CD = (CW + 3) / 4;             // dwords per chip row
+    static constexpr int LASTN = CW - 4 * (CD - 1);     // valid bytes of a chip row's last dword
+    static constexpr int CP0 = (CW + 15 + 3) & ~3;
+    static constexpr int CP = CP0 > 64 * KCW ? CP0 : 64 * KCW;     // chip plane pitch: a row's right padding is the next row's left padding
+    static constexpr int CH0 = 16;                      // leading zeros (row 0's left padding)
+    static constexpr int CWE = CW + (CW & 1);           // chip rows the product loop walks: two per trip (an all-zero row behind an odd chip)
+    static constexpr int CHB = (CH0 + CWE * CP + 16 + 15) & ~15;   // one chip plane (+ the read-ahead of the last row's last lane)
+    static constexpr int NPL = NULLS_ ? 3 : 1;          // chip planes: a', and for the null corrections (a^2 & 255)', (a^2 >> 8)'
+    static constexpr int VP = 33;                       // pitch (words) of the NCC surface
+    static constexpr int LDS_W = (16 * NTR + 1) * PW;   // (+ the row the product loop's zero chip row reads)
     static constexpr int LDS_VAL = 4 * 32 * VP;
-    static constexpr int OFF_CH = (LDS_W > LDS_VAL ? LDS_W : LDS_VAL);      // the surface reuses the tile's bytes once the sums are in registers
+    static constexpr int OFF_CH = ((LDS_W > LDS_VAL ? LDS_W : LDS_VAL) + 15) & ~15;      // the surface reuses the tile's bytes once the sums are in registers
     static constexpr int OFF_VIS = OFF_CH + NPL * CHB;
-    static constexpr int LDS = OFF_VIS + 128;
-    static constexpr int MINW = NULLS_ ? 2 : 3;            // occupancy target, waves per SIMD
+    static constexpr int OFF_PIV = OFF_VIS + 128;      // the pivots' starts, parked for wave 0's climbs
+    static constexpr int LDS = OFF_PIV + 512;
+    static constexpr int WGS = 163840 / ((LDS + 255) & ~255);      // workgroups per CU that LDS admits
+    static constexpr int MINW0 = NULLS_ ? 4 : 8;        // occupancy target, waves per SIMD (register budget) ...
+    static constexpr int MINW1 = (WGS * NW) / 4 > 0 ? (WGS * NW) / 4 : 1;                   // ... never above what LDS admits anyway
+    static constexpr int MINW = MINW0 < MINW1 ? MINW0 : MINW1;
 };
 
-// The constant band operands, one table per chip size (constant-initialised device data):
-//   hb[c][lane] : B operand of the row-box sums -- lane (s = lane & 31, h = lane >> 5), byte i of chunk c <-> window column
-//                 x = 16 KC h + 16 c + i :  1 if s <= x < s + CW
-//   vb[t][lane] : A operand of the vertical sums over row tile t -- lane (dy = lane & 31, h), byte i <-> K slot (h, i) <->
-//                 tile row y = 32 t + 8 (i >> 2) + 4 h + (i & 3) (where the accumulator layout of the row sums puts it):
-//                 1 if dy <= y < dy + CW
-template <int CW, int KC>
+// The constant band operands, one table per chip size (constant-initialised device data).  v_mfma_i32_16x16x64_i8: lane (n = lane & 15,
+// h = lane >> 4) holds byte i of K slot (h, i) of row / column n.
+//   hb[c][lane]     : B operand of the row-box sums -- byte i of chunk c <-> window column x = 16 w + 64 c + 16 h + i, cell column
+//                     s = 16 w + n:  1 if s <= x < s + CW  (the wave index cancels)
+//   vb[m][c][lane]  : A operand of the vertical sums -- cell row dy = 16 m + n; K slot (h, i) of chunk c <-> tile row
+//                     y = 64 c + 16 (i >> 2) + 4 h + (i & 3), where the accumulator layout of the row sums puts it (register i & 3 of row
+//                     tile 4 c + (i >> 2)):  1 if dy <= y < dy + CW
+template <int CW, int KCW, int KCV>
 struct alignas(16) Bands {
-    uint32_t hb[KC][64][4], vb[KC][64][4];
+    uint32_t hb[KCW][64][4], vb[2][KCV][64][4];
     constexpr Bands() : hb(), vb()
     {
-        for (int c = 0; c < KC; c++)
-            for (int l = 0; l < 64; l++) {
-                const int s = l & 31, h = l >> 5;
-                for (int i = 0; i < 16; i++) {
-                    const int x = 16 * KC * h + 16 * c + i;
-                    if (s <= x && x < s + CW) hb[c][l][i >> 2] |= 1u << (8 * (i & 3));
-                    const int y = 32 * c + 8 * (i >> 2) + 4 * h + (i & 3);
-                    if (s <= y && y < s + CW) vb[c][l][i >> 2] |= 1u << (8 * (i & 3));
+        for (int l = 0; l < 64; l++) {
+            const int n = l & 15, h = l >> 4;
+            for (int i = 0; i < 16; i++) {
+                for (int c = 0; c < KCW; c++) {
+                    const int x = 64 * c + 16 * h + i;
+                    if (n <= x && x < n + CW) hb[c][l][i >> 2] |= 1u << (8 * (i & 3));
                 }
+                for (int m = 0; m < 2; m++)
+                    for (int c = 0; c < KCV; c++) {
+                        const int dy = 16 * m + n, y = 64 * c + 16 * (i >> 2) + 4 * h + (i & 3);
+                        if (dy <= y && y < dy + CW) vb[m][c][l][i >> 2] |= 1u << (8 * (i & 3));
+                    }
             }
+        }
     }
 };
-template <int CW, int KC> __device__ const Bands<CW, KC> kBands{};
+template <int CW, int KCW, int KCV> __device__ const Bands<CW, KCW, KCV> kBands{};
 
 constexpr int kStatW = 8;
 
@@ -136,37 +158,27 @@ __device__ __forceinline__ v4i nullbytes(const v4i &a)
     }
     return z;
 }
-// byte planes 0 and 1 of the 16 row sums of an accumulator tile (values < 2^16), as the B operand of the vertical sums (signed bytes)
-__device__ __forceinline__ void planes2(const v16i &R, v4i &p0, v4i &p1)
+// The four registers of a 16 x 16 accumulator tile (rows 4 h + 0..3 of one 16-row tile) as ONE dword of each byte plane of the next
+// MFMA's B operand (signed bytes: ^ 0x80, except the single plane of values < 128)
+__device__ __forceinline__ void planes2(const v4i &R, uint32_t &p0, uint32_t &p1)
 {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t t01 = perm((uint32_t)R[4 * q + 1], (uint32_t)R[4 * q], 0x05010400u), t23 = perm((uint32_t)R[4 * q + 3], (uint32_t)R[4 * q + 2], 0x05010400u);
-        p0[q] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-        p1[q] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
-    }
+    const uint32_t t01 = perm((uint32_t)R[1], (uint32_t)R[0], 0x05010400u), t23 = perm((uint32_t)R[3], (uint32_t)R[2], 0x05010400u);   // [r0.b0, r1.b0, r0.b1, r1.b1]
+    p0 = perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+    p1 = perm(t23, t01, 0x07060302u) ^ 0x80808080u;
 }
-// ... planes 0, 1, 2 (values < 2^24)
-__device__ __forceinline__ void planes3(const v16i &R, v4i &p0, v4i &p1, v4i &p2)
+__device__ __forceinline__ void planes3(const v4i &R, uint32_t &p0, uint32_t &p1, uint32_t &p2)
 {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t r0 = (uint32_t)R[4 * q], r1 = (uint32_t)R[4 * q + 1], r2 = (uint32_t)R[4 * q + 2], r3 = (uint32_t)R[4 * q + 3];
-        const uint32_t t01 = perm(r1, r0, 0x05010400u), t23 = perm(r3, r2, 0x05010400u);
-        const uint32_t u01 = perm(r1, r0, 0x07030602u), u23 = perm(r3, r2, 0x07030602u);     // [r0.b2, r1.b2, r0.b3, r1.b3]
-        p0[q] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-        p1[q] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
-        p2[q] = (int)(perm(u23, u01, 0x05040100u) ^ 0x80808080u);
-    }
+    const uint32_t r0 = (uint32_t)R[0], r1 = (uint32_t)R[1], r2 = (uint32_t)R[2], r3 = (uint32_t)R[3];
+    const uint32_t t01 = perm(r1, r0, 0x05010400u), t23 = perm(r3, r2, 0x05010400u);
+    const uint32_t u01 = perm(r1, r0, 0x07030602u), u23 = perm(r3, r2, 0x07030602u);     // [r0.b2, r1.b2, r0.b3, r1.b3]
+    p0 = perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+    p1 = perm(t23, t01, 0x07060302u) ^ 0x80808080u;
+    p2 = perm(u23, u01, 0x05040100u) ^ 0x80808080u;
 }
-// ... plane 0 alone (values < 128: no sign to care about)
-__device__ __forceinline__ void planes1(const v16i &R, v4i &p0)
+__device__ __forceinline__ uint32_t planes1(const v4i &R)
 {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t t01 = perm((uint32_t)R[4 * q + 1], (uint32_t)R[4 * q], 0x05010400u), t23 = perm((uint32_t)R[4 * q + 3], (uint32_t)R[4 * q + 2], 0x05010400u);
-        p0[q] = (int)perm(t23, t01, 0x05040100u);
-    }
+    const uint32_t t01 = perm((uint32_t)R[1], (uint32_t)R[0], 0x05010400u), t23 = perm((uint32_t)R[3], (uint32_t)R[2], 0x05010400u);
+    return perm(t23, t01, 0x05040100u);
 }
 
 // diagnostics (MIMC3_MX_STATS): phase clocks stay in scalar registers and are stored once, by MIMC3_MX_STATS_OUT, before the kernel's normal exit
@@ -180,9 +192,9 @@ __device__ __forceinline__ void planes1(const v16i &R, v4i &p0)
     if (p.stats && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 7; i_++) p.stats[kStatW * (size_t)blockIdx.x + i_] = t_ph[i_]; }
 
 template <class C>
-__global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
+__global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
 {
-    constexpr int OCW = C::OCW, CW = C::CW, NPX = C::NPX, KC = C::KC, PW = C::PW, CP = C::CP, CH0 = C::CH0, VP = C::VP;
+    constexpr int OCW = C::OCW, CW = C::CW, NPX = C::NPX, KCW = C::KCW, KCV = C::KCV, NTR = C::NTR, PW = C::PW, CP = C::CP, CH0 = C::CH0, VP = C::VP, NT = C::NT;
     constexpr bool NULLS = C::NULLS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
     unsigned char *WT = smem;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + C::OFF_VIS);    // visited bits of the 32 tile rows
     unsigned long long t_prev = p.stats ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_ph[7] = {0, 0, 0, 0, 0, 0, 0};
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     int gidx = blockIdx.x;
     if (p.point_list) {                                      // list mode: the points another kernel handed over
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     if (gidx >= p.N) return;
     if (p.point_flags && p.point_flags[gidx] != (uint8_t)p.flag_value) return;      // flag mode: the points another kernel handed over
     auto hand_on = [&](uint8_t to) __attribute__((always_inline)) {
-        if (lane == 0) p.mx_flags[gidx] = to;
+        if (tid == 0) p.mx_flags[gidx] = to;
     };
 
     const unsigned char *chip_pl = p.swap ? p.p1 : p.p0;
@@ -228,18 +240,18 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     const SatT *sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
     // table queries: the chip's sums and null count, the null count of the window's written area (:869-886), and -- for the
     // closed-form T4 terms of the clean form -- the chip's last column and last row
-    const SatT chipQ = sat_box(sat_chip, p.sat_ws, cu0, cv0, CW, CW);
-    const SatT winQ = sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2);
+    const SatT chipQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0, CW, CW));
+    const SatT winQ = uni64(sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2));
     SatT colQ = 0, rowQ = 0;
     uint32_t corner = 0;
     if (!NULLS) {
-        colQ = sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW);
-        rowQ = sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1);
-        corner = chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1];
+        colQ = uni64(sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW));
+        rowQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1));
+        corner = (uint32_t)__builtin_amdgcn_readfirstlane((int)chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1]);
     }
-    // lane k = pivot k
-    int su = 0, sv = 0;
-    if (lane < npiv && npiv <= 64) { su = pv_g[2 * lane] + dx2; sv = pv_g[2 * lane + 1] + dy2; }
+    // the pivots (lane k of wave 0 = pivot k in the climbs): fetched with the header's loads, parked in LDS until the surface is there
+    int2 pv_mine = make_int2(0, 0);
+    if (wave == 0 && lane < npiv && npiv <= 64) pv_mine = *reinterpret_cast<const int2 *>(pv_g + 2 * lane);
 
     // ---- what this kernel takes -----------------------------------------------------------------------------------
     // The packed table fields are exact for boxes of at most 8,224 pixels (sum b < 2^21): larger written areas go on.
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         const float rc = (float)chip_nulls / (float)NPX;
         const float rw = (float)(win_nulls + Dx2 + Dy2 - 1) / (float)(Dx2 * Dy2);
         if (rc > max_ratio || rw > max_ratio) {
-            if (lane == 0) {
+            if (tid == 0) {
                 const float nanv = __builtin_nanf("");
                 p.out[3 * (size_t)gidx + 0] = nanv; p.out[3 * (size_t)gidx + 1] = nanv; p.out[3 * (size_t)gidx + 2] = -3.0f;
             }
@@ -273,20 +285,21 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     const uint32_t SX = (uint32_t)chipQ & ((1u << kSatSqShift8) - 1u);
     const uint32_t SXX = (uint32_t)(chipQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
 
-    // ---- stage the tile: window pixels (tx0 + x, ty0 + y), x < TW, y < TH, as signed bytes b - 128 ----------------------
+    // ---- stage the tile: window pixels (tx0 + x, ty0 + y), x < SW, y < KW, as signed bytes b - 128 (both waves) ---------------
     {
         const int gu = wu0 + tx0, gv = wv0 + ty0;
         const int sh = gu & 3;
         const uint32_t *gb = reinterpret_cast<const uint32_t *>(win_pl + (size_t)gv * Wp + (gu - sh));
         const int gp = Wp >> 2;
-        constexpr int NSEG = C::TW / 16, NTASK = C::KW * NSEG;       // rows >= KW are never weighted: left as they are
-        constexpr int NIT = (NTASK + 63) / 64;
+        constexpr int NSEG = C::SW / 16, NTASK = C::KW * NSEG;       // (rows >= KW and columns >= SW are only ever weighted 0: left as they are)
+        constexpr int NIT = (NTASK + NT - 1) / NT;
+        constexpr int KB = NIT < 4 ? NIT : 4;
 #pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += 4) {
-            uint32_t d[4][5];
+        for (int it0 = 0; it0 < NIT; it0 += KB) {
+            uint32_t d[KB][5];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t = lane + 64 * (it0 + k);
+            for (int k = 0; k < KB; k++) {
+                const int t = tid + NT * (it0 + k);
                 const int y = t / NSEG, q = t - NSEG * y;
                 const bool on = (it0 + k < NIT) && t < NTASK;
                 const uint32_t *g = gb + (size_t)(on ? y : 0) * gp + 4 * (on ? q : 0);
@@ -294,8 +307,8 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
                 for (int j = 0; j < 5; j++) d[k][j] = g[j];
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t = lane + 64 * (it0 + k);
+            for (int k = 0; k < KB; k++) {
+                const int t = tid + NT * (it0 + k);
                 const int y = t / NSEG, q = t - NSEG * y;
                 if ((it0 + k < NIT) && t < NTASK) {
                     uint4 w;
@@ -307,35 +320,40 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
                 }
             }
         }
-        // T4: the search area's last column and last row are never written (:869-886): nulls.  (What lies beyond them inside the tile
-        // only reaches cells no climb can touch.)
-        const int zx = Dx2 - 1 - tx0, zy = Dy2 - 1 - ty0;
-        if (zx < C::TW) for (int y = lane; y < C::KW; y += 64) WT[y * PW + zx] = 0x80;
-        if (zy < C::KW) for (int x = lane; x < C::TW / 4; x += 64) *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
     }
     // ---- chip planes: zeros, then CW rows of (a ^ 0x80) [and of the two byte planes of a^2] -------------------------------
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < (C::NPL * C::CHB) / 16; i += 64) reinterpret_cast<uint4 *>(CH)[i] = z4;
+        for (int i = tid; i < (C::NPL * C::CHB) / 16; i += NT) reinterpret_cast<uint4 *>(CH)[i] = z4;
+        if (wave == 0) reinterpret_cast<int2 *>(smem + C::OFF_PIV)[lane] = pv_mine;
+    }
+    __syncthreads();
+    {
+        // T4: the search area's last column and last row are never written (:869-886): nulls.  (What lies beyond them inside the tile
+        // only reaches cells no climb can touch.)
+        const int zx = Dx2 - 1 - tx0, zy = Dy2 - 1 - ty0;
+        if (zx < C::SW) for (int y = tid; y < C::KW; y += NT) WT[y * PW + zx] = 0x80;
+        if (zy < C::KW) for (int x = tid; x < C::SW / 4; x += NT) *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
         const int sh = cu0 & 3;
         const uint32_t *gb = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 - sh));
         const int gp = Wp >> 2;
-        constexpr int CD = C::CD, NTASK = CW * CD, NIT = (NTASK + 63) / 64;
+        constexpr int CD = C::CD, NTASK = CW * CD, NIT = (NTASK + NT - 1) / NT;
+        constexpr int KB = NIT < 5 ? NIT : 5;
         constexpr uint32_t LASTM = C::LASTN >= 4 ? 0xffffffffu : ((1u << (8 * C::LASTN)) - 1u);
 #pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += 5) {
-            uint32_t lo[5], hi[5];
+        for (int it0 = 0; it0 < NIT; it0 += KB) {
+            uint32_t lo[KB], hi[KB];
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int t = lane + 64 * (it0 + k);
+            for (int k = 0; k < KB; k++) {
+                const int t = tid + NT * (it0 + k);
                 const int r = t / CD, j = t - CD * r;
                 const bool on = (it0 + k < NIT) && t < NTASK;
                 const uint32_t *g = gb + (size_t)(on ? r : 0) * gp + (on ? j : 0);
                 lo[k] = g[0]; hi[k] = g[1];
             }
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int t = lane + 64 * (it0 + k);
+            for (int k = 0; k < KB; k++) {
+                const int t = tid + NT * (it0 + k);
                 const int r = t / CD, j = t - CD * r;
                 if ((it0 + k < NIT) && t < NTASK) {
                     const uint32_t a = alignb(hi[k], lo[k], sh);
@@ -355,121 +373,66 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     __syncthreads();
     MIMC3_MX_STAMP(0)
 
-    // lane (n, h): cell column n; byte i of K chunk c <-> window column 16 KC h + 16 c + i (a lane's chunks are contiguous)
-    const int n = lane & 31, h = lane >> 5;
-    const unsigned char *arow = WT + n * PW + 16 * KC * h;
-    const int boff = CH0 + 16 * KC * h - n;
+    // lane (n, h) of wave w: cell column s = 16 w + n; byte i of K chunk c <-> window column 16 w + 64 c + 16 h + i
+    const int n = lane & 15, h = lane >> 4;
+    const unsigned char *arow = WT + n * PW + 16 * wave + 16 * h;       // A operand: tile row r + 16 mt + n
+    const int boff = CH0 + 16 * h - n;                                   // B operand: chip-row bytes 64 c + 16 h - n + i
     const uint32_t bsh = (uint32_t)boff & 3u;
     const unsigned char *brow = CH + (boff & ~3);
-    auto load_a = [&](int r, v4i (&a)[KC]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < KC; c++) a[c] = *reinterpret_cast<const v4i *>(arow + r * PW + 16 * c);
-    };
-
-    // ---- window-side box sums of every cell: sum b, sum b^2 (and the null count) -------------------------------------------
-    //      row-box sums R[y][s] = sum_{x = s}^{s + CW - 1} q[y][x] by MFMA (A = the tile's rows, B = the band of ones), then
-    //      Box[dy][s] = sum_{y = dy}^{dy + CW - 1} R[y][s] by MFMA (A = the band of ones, B = the byte planes of R: the
-    //      accumulator layout has R's rows where a B operand has its K index)
-    v16i boxb, boxq, boxz = {0};
-    {
-        const Bands<CW, KC> &bd = kBands<CW, KC>;
-        v4i hb[KC];
-#pragma unroll
-        for (int c = 0; c < KC; c++) hb[c] = *reinterpret_cast<const v4i *>(&bd.hb[c][lane][0]);
-        {   // sum b (and the null count)
-            v16i v0 = {0}, v1 = {0};
-#pragma unroll
-            for (int t = 0; t < KC; t++) {
-                const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[t][lane][0]);
-                v4i a[KC];
-                load_a(32 * t, a);
-                v16i R = {0};
-#pragma unroll
-                for (int c = 0; c < KC; c++) R = mfma(a[c], hb[c], R);
-#pragma unroll
-                for (int i = 0; i < 16; i++) R[i] += 128 * CW;
-                v4i p0, p1;
-                planes2(R, p0, p1);
-                v0 = mfma(vb, p0, v0); v1 = mfma(vb, p1, v1);
-                if (NULLS) {
-                    v16i Z = {0};
-#pragma unroll
-                    for (int c = 0; c < KC; c++) Z = mfma(nullbytes(a[c]), hb[c], Z);
-                    v4i pz;
-                    planes1(Z, pz);
-                    boxz = mfma(vb, pz, boxz);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) boxb[i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW);
-        }
-        {   // sum b^2
-            v16i v0 = {0}, v1 = {0}, v2 = {0};
-#pragma unroll
-            for (int t = 0; t < KC; t++) {
-                const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[t][lane][0]);
-                v4i a[KC];
-                load_a(32 * t, a);
-                v16i Rl = {0}, Rh = {0};
-#pragma unroll
-                for (int c = 0; c < KC; c++) {
-                    v4i lo, hi;
-                    squares(a[c], lo, hi);
-                    Rl = mfma(lo, hb[c], Rl); Rh = mfma(hi, hb[c], Rh);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) Rl[i] = (Rl[i] + 128 * CW) + 256 * (Rh[i] + 128 * CW);
-                v4i p0, p1, p2;
-                planes3(Rl, p0, p1, p2);
-                v0 = mfma(vb, p0, v0); v1 = mfma(vb, p1, v1); v2 = mfma(vb, p2, v2);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) boxq[i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW) + 65536 * (v2[i] + 128 * CW);
-        }
-    }
-    MIMC3_MX_STAMP(1)
 
     // ---- the product surface (and the null corrections) ------------------------------------------------------------------
     //      Software-pipelined by hand: the LDS reads of chip row r + 1 are in flight while row r's MFMAs issue (left to the compiler,
-    //      every row waited for its own reads: one LDS latency per row, the MFMA pipe a sixth busy).
-    v16i acc = {0}, accz = {0}, accl = {0}, acch = {0};
+    //      every row waited for its own reads: one LDS latency per row).  No branch inside the loop: with conditional reads the
+    //      compiler's wait counts assume the shorter queue; an odd chip is followed by an all-zero row, whose products add nothing.
+    v4i acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accz[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acch[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     (void)accz; (void)accl; (void)acch;
     {
-        struct RowOps { v4i a[KC]; uint32_t d[C::NPL][C::ND]; };
+        struct RowOps { v4i a[2][KCW]; uint32_t d[C::NPL][KCW][5]; };
         auto issue = [&](int r, RowOps &o) __attribute__((always_inline)) {
-            load_a(r, o.a);
 #pragma unroll
-            for (int pl = 0; pl < C::NPL; pl++) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r);
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int k = 0; k < C::ND; k++) o.d[pl][k] = q[k];
-            }
+                for (int c = 0; c < KCW; c++) o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
+#pragma unroll
+            for (int pl = 0; pl < C::NPL; pl++)
+#pragma unroll
+                for (int c = 0; c < KCW; c++) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r + 64 * c);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) o.d[pl][c][k] = q[k];
+                }
         };
-        auto shifted = [&](const uint32_t (&d)[C::ND], v4i (&b)[KC]) __attribute__((always_inline)) {
+        auto shifted = [&](const uint32_t (&d)[KCW][5], v4i (&b)[KCW]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < KC; c++)
+            for (int c = 0; c < KCW; c++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[4 * c + k + 1], d[4 * c + k], bsh);
+                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[c][k + 1], d[c][k], bsh);
         };
         auto consume = [&](const RowOps &o) __attribute__((always_inline)) {
-            v4i b[KC];
+            v4i b[KCW];
             shifted(o.d[0], b);
 #pragma unroll
-            for (int c = 0; c < KC; c++) acc = mfma(o.a[c], b[c], acc);
-            if constexpr (NULLS) {
-                v4i z[KC];
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int c = 0; c < KC; c++) { z[c] = nullbytes(o.a[c]); accz = mfma(z[c], b[c], accz); }
+                for (int c = 0; c < KCW; c++) acc[m] = mfma(o.a[m][c], b[c], acc[m]);
+            if constexpr (NULLS) {
+                v4i z[2][KCW];
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int c = 0; c < KCW; c++) { z[m][c] = nullbytes(o.a[m][c]); accz[m] = mfma(z[m][c], b[c], accz[m]); }
                 shifted(o.d[1], b);
 #pragma unroll
-                for (int c = 0; c < KC; c++) accl = mfma(z[c], b[c], accl);
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int c = 0; c < KCW; c++) accl[m] = mfma(z[m][c], b[c], accl[m]);
                 shifted(o.d[2], b);
 #pragma unroll
-                for (int c = 0; c < KC; c++) acch = mfma(z[c], b[c], acch);
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int c = 0; c < KCW; c++) acch[m] = mfma(z[m][c], b[c], acch[m]);
             }
         };
-        // (no branch inside the loop: with conditional reads the compiler's wait counts assume the shorter queue and every row waits for the
-        //  reads issued behind it; an odd chip is followed by an all-zero row, whose products add nothing)
         RowOps o0, o1;
         issue(0, o0);
 #pragma unroll 1
@@ -484,41 +447,132 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    MIMC3_MX_STAMP(1)
+
+    // ---- window-side box sums of the wave's 32 x 16 cells: sum b, sum b^2 (and the null count) ------------------------------------
+    //      row-box sums R[y][s] = sum_{x = s}^{s + CW - 1} q[y][x] by MFMA (A = 16 tile rows, B = the band of ones), then
+    //      Box[dy][s] = sum_{y = dy}^{dy + CW - 1} R[y][s] by MFMA (A = the band of ones, B = the byte planes of R: the four registers
+    //      of a 16-row accumulator tile are one dword of the B operand -- the accumulator layout has R's rows where B has its K index)
+    v4i boxb[2], boxq[2], boxz[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    {
+        const Bands<CW, KCW, KCV> &bd = kBands<CW, KCW, KCV>;
+        v4i hb[KCW];
+#pragma unroll
+        for (int c = 0; c < KCW; c++) hb[c] = *reinterpret_cast<const v4i *>(&bd.hb[c][lane][0]);
+        auto tile_a = [&](int t, v4i (&a)[KCW]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < KCW; c++) a[c] = *reinterpret_cast<const v4i *>(arow + 16 * t * PW + 64 * c);
+        };
+        const v4i zero4 = {0, 0, 0, 0};
+        {   // sum b (and the null count)
+            v4i p0[KCV], p1[KCV], pz[KCV];
+#pragma unroll
+            for (int t = 0; t < 4 * KCV; t++) {
+                uint32_t q0 = 0, q1 = 0, qz = 0;
+                if (t < NTR) {
+                    v4i a[KCW];
+                    tile_a(t, a);
+                    v4i R = zero4;
+#pragma unroll
+                    for (int c = 0; c < KCW; c++) R = mfma(a[c], hb[c], R);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) R[i] += 128 * CW;
+                    planes2(R, q0, q1);
+                    if (NULLS) {
+                        v4i Z = zero4;
+#pragma unroll
+                        for (int c = 0; c < KCW; c++) Z = mfma(nullbytes(a[c]), hb[c], Z);
+                        qz = planes1(Z);
+                    }
+                }
+                p0[t >> 2][t & 3] = (int)q0; p1[t >> 2][t & 3] = (int)q1; pz[t >> 2][t & 3] = (int)qz;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                v4i v0 = zero4, v1 = zero4;
+#pragma unroll
+                for (int c = 0; c < KCV; c++) {
+                    const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[m][c][lane][0]);
+                    v0 = mfma(vb, p0[c], v0); v1 = mfma(vb, p1[c], v1);
+                    if (NULLS) boxz[m] = mfma(vb, pz[c], boxz[m]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) boxb[m][i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW);
+            }
+        }
+        {   // sum b^2
+            v4i p0[KCV], p1[KCV], p2[KCV];
+#pragma unroll
+            for (int t = 0; t < 4 * KCV; t++) {
+                uint32_t q0 = 0, q1 = 0, q2 = 0;
+                if (t < NTR) {
+                    v4i a[KCW];
+                    tile_a(t, a);
+                    v4i Rl = zero4, Rh = zero4;
+#pragma unroll
+                    for (int c = 0; c < KCW; c++) {
+                        v4i lo, hi;
+                        squares(a[c], lo, hi);
+                        Rl = mfma(lo, hb[c], Rl); Rh = mfma(hi, hb[c], Rh);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) Rl[i] = (Rl[i] + 128 * CW) + 256 * (Rh[i] + 128 * CW);
+                    planes3(Rl, q0, q1, q2);
+                }
+                p0[t >> 2][t & 3] = (int)q0; p1[t >> 2][t & 3] = (int)q1; p2[t >> 2][t & 3] = (int)q2;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                v4i v0 = zero4, v1 = zero4, v2 = zero4;
+#pragma unroll
+                for (int c = 0; c < KCV; c++) {
+                    const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[m][c][lane][0]);
+                    v0 = mfma(vb, p0[c], v0); v1 = mfma(vb, p1[c], v1); v2 = mfma(vb, p2[c], v2);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) boxq[m][i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW) + 65536 * (v2[i] + 128 * CW);
+            }
+        }
+    }
+
     MIMC3_MX_STAMP(2)
     __syncthreads();                                        // the tile's bytes become the NCC surface
 
-    // ---- NCC of the 16 cells of this lane (:734): exact integer sums, the f64 formula rounded to f32 ------------------------------
+    // ---- NCC of the 8 cells of this lane (:734): exact integer sums, the f64 formula rounded to f32 ------------------------------
     //   reference:  (float)( num / sqrt(P) ),  num = n sxy - sx sy  and  va = n sxx - sx^2,  vb = n syy - sy^2  exact integers in f64,
     //               P = va * vb rounded once, sqrt and the division correctly rounded: the f64 quotient Qd is within 2^-51 of num / sqrt(P).
-    //   here:       r = v_rsq_f64(P) refined by one Newton step (relative error <= 1.5 e^2 + a few 2^-53, e = the instruction's error,
-    //               2^-23 by the ISA's "2^29 ulp"), Q' = num * r'.  Q' and Qd round to the SAME f32 unless an f32 rounding boundary lies
-    //               between them: a cell whose Q' is within 2^-40 |Q'| of a boundary (or whose P is not positive: the reference's
-    //               inf / NaN cases) is redone with the reference's own operations.  2^-15 of the cells; every bit of every cell is
-    //               the reference's either way (tests/test_mx_finish.py brute-forces the guard on the device).
+    //   here:       r = v_rsq_f64(P) refined by one Newton step (relative error 2^-47.8 measured, tools/probes/mx_finish.hip; the
+    //               instruction alone 2^-24.2), Q' = num * r'.  Q' and Qd round to the SAME f32 unless an f32 rounding boundary lies
+    //               between them: a cell whose Q' is within 2^13 f64 ulps (2^-40 relative) of a boundary, or whose P is not positive (the
+    //               reference's inf / NaN cases), is redone with the reference's own operations.  2^-15 of the cells; over 2^34 random
+    //               cells the farthest one whose two results differed lay 7 ulps from its boundary.
     {
-        const int cx = tx0 + n;
+        const int sx_col = 16 * wave + n, cx = tx0 + sx_col;
         // clean form, T4 in closed form: a cell whose box reaches the never-written last column (row) loses the chip's last column (row)
-        const uint32_t cS = (uint32_t)colQ & ((1u << kSatSqShift8) - 1u), cSS = (uint32_t)(colQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
-        const uint32_t rS = (uint32_t)rowQ & ((1u << kSatSqShift8) - 1u), rSS = (uint32_t)(rowQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+        uint32_t cS = (uint32_t)colQ & ((1u << kSatSqShift8) - 1u), cSS = (uint32_t)(colQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+        uint32_t rS = (uint32_t)rowQ & ((1u << kSatSqShift8) - 1u), rSS = (uint32_t)(rowQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
+        uint32_t SXo = SX, SXXo = SXX;
+        // (opaque here: left alone, the compiler forms the f64 constants below in the header and carries twelve registers through every phase)
+        asm volatile("" : "+s"(cS), "+s"(cSS), "+s"(rS), "+s"(rSS), "+s"(SXo), "+s"(SXXo));
         const bool colT4 = !NULLS && cx == csx - 2;
         const int rT4 = NULLS ? -1 : csy - 2 - ty0;         // tile row of the cells that reach the never-written last row
         // (n, sx, va) of this lane's cells: off / on the T4 row
         double dn0, dsx0, va0, dn1, dsx1, va1;
         {
-            const int n0 = NPX - (colT4 ? CW : 0), sx0 = (int)SX - (colT4 ? (int)cS : 0), sxx0 = (int)SXX - (colT4 ? (int)cSS : 0);
+            const int n0 = NPX - (colT4 ? CW : 0), sx0 = (int)SXo - (colT4 ? (int)cS : 0), sxx0 = (int)SXXo - (colT4 ? (int)cSS : 0);
             const int n1 = n0 - CW + (colT4 ? 1 : 0), sx1 = sx0 - (int)rS + (colT4 ? (int)corner : 0), sxx1 = sxx0 - (int)rSS + (colT4 ? (int)(corner * corner) : 0);
             dn0 = (double)n0; dsx0 = (double)sx0; va0 = dn0 * (double)sxx0 - dsx0 * dsx0;
             dn1 = (double)n1; dsx1 = (double)sx1; va1 = dn1 * (double)sxx1 - dsx1 * dsx1;
         }
-        auto cell_in = [&](int i, double &dn, double &dsx, double &va, int &sxy, int &sy, int &syy) __attribute__((always_inline)) {
-            const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
-            sy = boxb[i]; syy = boxq[i];
-            sxy = acc[i] + 128 * ((int)SX + sy) - 16384 * NPX;
+        auto cell_in = [&](int m, int i, double &dn, double &dsx, double &va, int &sxy, int &sy, int &syy) __attribute__((always_inline)) {
+            const int ry = 16 * m + 4 * h + i;
+            sy = boxb[m][i]; syy = boxq[m][i];
+            sxy = acc[m][i] + 128 * ((int)SXo + sy) - 16384 * NPX;
             if (NULLS) {
-                const int nz = boxz[i];
-                const int ca = accz[i] + 128 * nz, caa = (accl[i] + 128 * nz) + 256 * (acch[i] + 128 * nz);
-                dn = (double)(NPX - nz); dsx = (double)((int)SX - ca);
-                va = dn * (double)((int)SXX - caa) - dsx * dsx;
+                const int nz = boxz[m][i];
+                const int ca = accz[m][i] + 128 * nz, caa = (accl[m][i] + 128 * nz) + 256 * (acch[m][i] + 128 * nz);
+                dn = (double)(NPX - nz); dsx = (double)((int)SXo - ca);
+                va = dn * (double)((int)SXXo - caa) - dsx * dsx;
             } else {
                 const bool rowT4 = ry == rT4;
                 dn = rowT4 ? dn1 : dn0; dsx = rowT4 ? dsx1 : dsx0; va = rowT4 ? va1 : va0;
@@ -526,10 +580,10 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
         };
         uint32_t amb = 0u;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
+        for (int ci = 0; ci < 8; ci++) {
+            const int m = ci >> 2, i = ci & 3, ry = 16 * m + 4 * h + i;
             double dn, dsx, va; int sxy, sy, syy;
-            cell_in(i, dn, dsx, va, sxy, sy, syy);
+            cell_in(m, i, dn, dsx, va, sxy, sy, syy);
             const double dsy = (double)sy;
             const double num = dn * (double)sxy - dsx * dsy;
             const double P = va * (dn * (double)syy - dsy * dsy);
@@ -539,25 +593,26 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
             const double r1 = __builtin_fma(0.5 * r, e2, r);
             const double q = num * r1;
             const uint32_t low = ((uint32_t)__double2loint(q) & 0x1fffffffu) - (0x10000000u - 0x2000u);     // distance to the f32 rounding boundary, + 2^13
-            if (!(P > 0.0) || low <= 0x4000u) amb |= 1u << i;
-            val[ry * VP + n] = (float)q;
+            if (!(P > 0.0) || low <= 0x4000u) amb |= 1u << ci;
+            val[ry * VP + sx_col] = (float)q;
         }
         if (__any(amb != 0u)) {                            // rare (2^-15 of the cells): the reference's own operations
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (!__any((amb >> i) & 1u)) continue;
+            for (int ci = 0; ci < 8; ci++) {
+                if (!__any((amb >> ci) & 1u)) continue;
+                const int m = ci >> 2, i = ci & 3, ry = 16 * m + 4 * h + i;
                 double dn, dsx, va; int sxy, sy, syy;
-                cell_in(i, dn, dsx, va, sxy, sy, syy);
-                const int ry = 8 * (i >> 2) + 4 * h + (i & 3);
+                cell_in(m, i, dn, dsx, va, sxy, sy, syy);
                 const double dsy = (double)sy;
                 const double num = dn * (double)sxy - dsx * dsy;
                 const double den = sqrt(va * (dn * (double)syy - dsy * dsy));
-                if ((amb >> i) & 1u) val[ry * VP + n] = (float)(num / den);
+                if ((amb >> ci) & 1u) val[ry * VP + sx_col] = (float)(num / den);
             }
         }
     }
     __syncthreads();
     MIMC3_MX_STAMP(3)
+    if (wave != 0) return;                                  // the sequential part needs one wave (lane k = pivot k)
 
     // ---- the climbs (lane k = pivot k) on the complete surface; trajectories as 4-bit codes per scan -------------------------
     auto inside = [&](int pu, int pvv) __attribute__((always_inline)) -> bool {     // the reference's boundary test (:703), true = scan allowed
@@ -567,6 +622,11 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
     auto relx = [&](int pu) __attribute__((always_inline)) -> int { return pu - OCW - tx0; };
     auto rely = [&](int pvv) __attribute__((always_inline)) -> int { return pvv - OCW - ty0; };
     constexpr int kSpecRounds = 16;
+    int su, sv;
+    {
+        const int2 pv = reinterpret_cast<const int2 *>(smem + C::OFF_PIV)[lane];
+        su = pv.x + dx2; sv = pv.y + dy2;
+    }
     const int start_u = su, start_v = sv;
     bool alive = lane < npiv && inside(su, sv);
     bool left = false;                                       // a scan would leave the tile
@@ -681,7 +741,7 @@ __global__ __launch_bounds__(64, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
             peak_u = (int)(pk & 0xffffu); peak_v = (int)(pk >> 16); best = bv;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                          // (one wave: its LDS operations are performed in order)
     // ---- 3x3 quadratic fit (:757-788), the reference's arithmetic value by value (match_px_kernel.hip) ------------------------------
     if (lane < 5) {
         float n9[9];
@@ -737,7 +797,7 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
         (void)hipMemsetAsync(d_stats, 0, kStatW * sizeof(unsigned long long) * (size_t)nb, stream);
     }
     a.stats = want_stats ? d_stats : nullptr;
-    hipLaunchKernelGGL(match_ncc_dlc_mx<C>, dim3(nb), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(match_ncc_dlc_mx<C>, dim3(nb), dim3(C::NT), 0, stream, a);
     if (want_stats) {
         (void)hipStreamSynchronize(stream);
         unsigned long long *hh = (unsigned long long *)malloc(kStatW * sizeof(unsigned long long) * (size_t)nb);
@@ -754,7 +814,7 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
             for (int i = 0; i < a.N; i++) { nn += hf[i] == kMxNulls; nr += hf[i] == kMxRest; }
             free(hf);
         }
-        fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f box sums %.0f products %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
+        fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f products %.0f box sums %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
                 C::OCW, C::NULLS ? "nulls" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
     }
     return hipGetLastError();
@@ -768,7 +828,21 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half)
     if (!off) return false;
     if (win_half > 0) return false;                   // full-square search areas (control-point stage): many pivots, not this kernel
     (void)max_npiv;
-    return ocw == 16;
+    return ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40;
+}
+
+template <bool NULLS>
+static hipError_t launch_form(const MatchU8Args &a, hipStream_t stream)
+{
+    switch (a.ocw) {
+    case 7: return mx::launch_one<mx::Cfg<7, NULLS>>(a, stream);
+    case 15: return mx::launch_one<mx::Cfg<15, NULLS>>(a, stream);
+    case 16: return mx::launch_one<mx::Cfg<16, NULLS>>(a, stream);
+    case 30: return mx::launch_one<mx::Cfg<30, NULLS>>(a, stream);
+    case 32: return mx::launch_one<mx::Cfg<32, NULLS>>(a, stream);
+    case 40: return mx::launch_one<mx::Cfg<40, NULLS>>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // Two launches: the clean form over all points (or the caller's list), the NULLS form over the points it flagged.  Points neither
@@ -777,18 +851,10 @@ hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
     if (!a.mx_flags || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
-    hipError_t e = hipSuccess;
-    switch (a.ocw) {
-    case 16: e = mx::launch_one<mx::Cfg<16, false>>(a, stream); break;
-    default: return hipErrorInvalidValue;
-    }
+    hipError_t e = launch_form<false>(a, stream);
     if (e != hipSuccess) return e;
     a.point_flags = a.mx_flags; a.flag_value = kMxNulls;
-    switch (a.ocw) {
-    case 16: e = mx::launch_one<mx::Cfg<16, true>>(a, stream); break;
-    default: return hipErrorInvalidValue;
-    }
-    return e;
+    return launch_form<true>(a, stream);
 }
 
 }  // namespace mimc3
