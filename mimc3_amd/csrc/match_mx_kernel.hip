@@ -13,16 +13,18 @@
 //   * window-side sums  sy = sum_box b, syy = sum_box b^2  of every cell: row-box sums by MFMA against a band of ones
 //     (b^2 as two byte planes), then the vertical CW-row sums by a second MFMA against a band of ones (the row sums split
 //     into byte planes; an accumulator tile is the next MFMA's B operand as it stands: its rows are the K index);
-//   * window nulls (NULLS form): a null pixel q of the box takes a(q) out of n, sx, sxx.  With z = [b == 0] as the A operand
-//     the three corrections are three more correlations on the same pipe:  sum z (box count),  sum a z  (same B operand as
-//     sxy),  sum a^2 z  (a^2 as two byte planes of the CHIP operand).  The never-written last window row / column (T4) are
-//     zeros of the staged tile, i.e. nulls like any other; the clean form applies them in closed form (they take the chip's
-//     last column / row out of n, sx, sxx);
+//   * null pixels (general form).  A window null q of the box takes a(q) out of n, sx, sxx: with zb = [b == 0] as the A operand the
+//     corrections are three more correlations on the same pipe -- sum zb (box count), sum a zb (same B operand as sxy), sum a^2 zb
+//     (a^2 as two byte planes, formed from the B operand in registers).  A chip null p takes b(p) out of sy, syy: with za = [a == 0]
+//     as the B operand -- formed from the Toeplitz rows of the chip rows that hold nulls, the only ones visited -- sum b za,
+//     sum b^2 za (b^2 as two byte planes of the A operand), and sum zb za for n.  The never-written last window row / column (T4) are
+//     zeros of the staged tile, i.e. nulls like any other when the window's nulls are correlated anyway; otherwise (and in the clean
+//     form) they are applied in closed form: they take the chip's last column / row out of n, sx, sxx;
 //   * the NCC of all 1,024 cells (:734, f64, no contraction) -> one f32 surface in LDS;
 //   * the climb of every pivot on the complete surface (lane k = pivot k), the exact replay of the reference's sequential
 //     visited-set semantics (:691-753) and the 3x3 fit (:757-788) as in match_px_kernel.hip.
 // What this kernel does not take it hands on (device lists, no host round trip): points whose window holds nulls go from the
-// clean form to the NULLS form; chips with nulls, more than 64 pivots, pivot sets wider than the tile, climbs that leave the
+// clean form to the general form; more than 64 pivots, pivot sets wider than the tile, climbs that leave the
 // tile or outlast the 16 recorded scans go to the register-tiled kernel (match_px_kernel.hip) in list mode.
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -64,10 +66,10 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 #undef MIMC3_MX_ARGMAX_STEP
 }
 
-template <int OCW_, bool NULLS_>
+template <int OCW_, bool GEN_>
 struct Cfg {
     static constexpr int OCW = OCW_, CW = 2 * OCW_ + 1, NPX = CW * CW;
-    static constexpr bool NULLS = NULLS_;
+    static constexpr bool GEN = GEN_;                   // the general form: null pixels in the window and / or in the chip
     // Two waves per grid point: wave w owns the cell columns [16 w, 16 w + 16) of the 32 x 32 tile (two 16 x 16 MFMA tiles, rows
     // 0..15 and 16..31), so each wave carries half the accumulators.  The front phases run on both, the climb / replay / fit on wave 0
     // after wave 1 has left: registers per wave, not LDS, bound how many points a CU works on.
@@ -87,22 +89,23 @@ struct Cfg {
     static constexpr int CH0 = 16;                      // leading zeros (row 0's left padding)
     static constexpr int CWE = CW + (CW & 1);           // chip rows the product loop walks: two per trip (an all-zero row behind an odd chip)
     static constexpr int CHB = (CH0 + CWE * CP + 16 + 15) & ~15;   // one chip plane (+ the read-ahead of the last row's last lane)
-    static constexpr int NPL = NULLS_ ? 3 : 1;          // chip planes: a', and for the null corrections (a^2 & 255)', (a^2 >> 8)'
     static constexpr int VP = 33;                       // pitch (words) of the NCC surface
     static constexpr int LDS_W = (16 * NTR + 1) * PW;   // (+ the row the product loop's zero chip row reads)
     static constexpr int LDS_VAL = 4 * 32 * VP;
     static constexpr int OFF_CH = ((LDS_W > LDS_VAL ? LDS_W : LDS_VAL) + 15) & ~15;      // the surface reuses the tile's bytes once the sums are in registers
-    static constexpr int OFF_VIS = OFF_CH + NPL * CHB;
+    static constexpr int OFF_VIS = OFF_CH + CHB;
     static constexpr int OFF_PIV = OFF_VIS + 128;      // the pivots' starts, parked for wave 0's climbs
-    static constexpr int LDS = OFF_PIV + 512;
+    static constexpr int OFF_RM = OFF_PIV + 512;       // general form: bit r = chip row r holds a null pixel
+    static constexpr int LDS = OFF_RM + 16;
     static constexpr int WGS = 163840 / ((LDS + 255) & ~255);      // workgroups per CU that LDS admits
-    static constexpr int MINW0 = NULLS_ ? 4 : 8;        // occupancy target, waves per SIMD (register budget) ...
+    static constexpr int MINW0 = GEN_ ? 3 : 8;          // occupancy target, waves per SIMD (register budget) ...
     static constexpr int MINW1 = (WGS * NW) / 4 > 0 ? (WGS * NW) / 4 : 1;                   // ... never above what LDS admits anyway
     static constexpr int MINW = MINW0 < MINW1 ? MINW0 : MINW1;
 };
 
 // The constant band operands, one table per chip size (constant-initialised device data).  v_mfma_i32_16x16x64_i8: lane (n = lane & 15,
 // h = lane >> 4) holds byte i of K slot (h, i) of row / column n.
+//   bm[c][lane]     : 0xff in the bytes of a chip-row B operand that hold chip pixels (the others are Toeplitz padding) -- the same bytes as hb
 //   hb[c][lane]     : B operand of the row-box sums -- byte i of chunk c <-> window column x = 16 w + 64 c + 16 h + i, cell column
 //                     s = 16 w + n:  1 if s <= x < s + CW  (the wave index cancels)
 //   vb[m][c][lane]  : A operand of the vertical sums -- cell row dy = 16 m + n; K slot (h, i) of chunk c <-> tile row
@@ -110,15 +113,15 @@ struct Cfg {
 //                     tile 4 c + (i >> 2)):  1 if dy <= y < dy + CW
 template <int CW, int KCW, int KCV>
 struct alignas(16) Bands {
-    uint32_t hb[KCW][64][4], vb[2][KCV][64][4];
-    constexpr Bands() : hb(), vb()
+    uint32_t hb[KCW][64][4], vb[2][KCV][64][4], bm[KCW][64][4];
+    constexpr Bands() : hb(), vb(), bm()
     {
         for (int l = 0; l < 64; l++) {
             const int n = l & 15, h = l >> 4;
             for (int i = 0; i < 16; i++) {
                 for (int c = 0; c < KCW; c++) {
                     const int x = 64 * c + 16 * h + i;
-                    if (n <= x && x < n + CW) hb[c][l][i >> 2] |= 1u << (8 * (i & 3));
+                    if (n <= x && x < n + CW) { hb[c][l][i >> 2] |= 1u << (8 * (i & 3)); bm[c][l][i >> 2] |= 0xffu << (8 * (i & 3)); }
                 }
                 for (int m = 0; m < 2; m++)
                     for (int c = 0; c < KCV; c++) {
@@ -195,7 +198,7 @@ template <class C>
 __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p)
 {
     constexpr int OCW = C::OCW, CW = C::CW, NPX = C::NPX, KCW = C::KCW, KCV = C::KCV, NTR = C::NTR, PW = C::PW, CP = C::CP, CH0 = C::CH0, VP = C::VP, NT = C::NT;
-    constexpr bool NULLS = C::NULLS;
+    constexpr bool GEN = C::GEN;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
     unsigned char *WT = smem;
     float *val = reinterpret_cast<float *>(smem);                       // [32][VP] NCC surface (over the tile, once it is consumed)
@@ -241,21 +244,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     // table queries: the chip's sums and null count, the null count of the window's written area (:869-886), and -- for the
     // closed-form T4 terms of the clean form -- the chip's last column and last row
     const SatT chipQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0, CW, CW));
-    const SatT winQ = uni64(sat_box(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2));
-    SatT colQ = 0, rowQ = 0;
-    uint32_t corner = 0;
-    if (!NULLS) {
-        colQ = uni64(sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW));
-        rowQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1));
-        corner = (uint32_t)__builtin_amdgcn_readfirstlane((int)chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1]);
-    }
+    const SatT colQ = uni64(sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW));
+    const SatT rowQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1));
+    const uint32_t corner = (uint32_t)__builtin_amdgcn_readfirstlane((int)chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1]);
     // the pivots (lane k of wave 0 = pivot k in the climbs): fetched with the header's loads, parked in LDS until the surface is there
     int2 pv_mine = make_int2(0, 0);
     if (wave == 0 && lane < npiv && npiv <= 64) pv_mine = *reinterpret_cast<const int2 *>(pv_g + 2 * lane);
 
     // ---- what this kernel takes -----------------------------------------------------------------------------------
-    // The packed table fields are exact for boxes of at most 8,224 pixels (sum b < 2^21): larger written areas go on.
-    const bool area_ok = (2 * dx2) * (2 * dy2) <= 8224;
     // the tile: all reachable cells if they fit, else centred on the pivots' starts (a scan that leaves it hands the point on)
     int tx0 = 1, ty0 = 1;
     bool fits = true;
@@ -265,9 +261,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         if (csx - 2 > 32) { tx0 = min(max((lox + hix) / 2 - 15, 1), csx - 2 - 31); fits = fits && lox - 1 >= tx0 && hix + 1 <= tx0 + 31; }
         if (csy - 2 > 32) { ty0 = min(max((loy + hiy) / 2 - 15, 1), csy - 2 - 31); fits = fits && loy - 1 >= ty0 && hiy + 1 <= ty0 + 31; }
     }
-    const int chip_nulls = (int)(chipQ >> kSatNullShift8), win_nulls = (int)(winQ >> kSatNullShift8);
-    if (npiv > 64 || !area_ok || !fits || chip_nulls != 0) { hand_on(kMxRest); return; }
-    if (!NULLS && win_nulls != 0) { hand_on(kMxNulls); return; }
+    const int chip_nulls = (int)(chipQ >> kSatNullShift8);
+    const int win_nulls = __builtin_amdgcn_readfirstlane(sat_nulls_u8(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2, lane));    // (exact for any window size)
+    if (npiv > 64 || !fits) { hand_on(kMxRest); return; }
+    if (!GEN && (win_nulls != 0 || chip_nulls != 0)) { hand_on(kMxNulls); return; }
+    // general form: wn = the written area of the window holds nulls (then the never-written last row / column are nulls like any other,
+    // else they are applied in closed form as in the clean form); cn = the chip holds nulls
+    const bool wn = GEN && win_nulls != 0, cn = GEN && chip_nulls != 0;
 
     // ---- validity (a6, :605-644): nulls of the chip / of the whole Dy2 x Dx2 search area (its last row and column are never written: zeros)
     {
@@ -324,8 +324,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     // ---- chip planes: zeros, then CW rows of (a ^ 0x80) [and of the two byte planes of a^2] -------------------------------
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < (C::NPL * C::CHB) / 16; i += NT) reinterpret_cast<uint4 *>(CH)[i] = z4;
+        for (int i = tid; i < C::CHB / 16; i += NT) reinterpret_cast<uint4 *>(CH)[i] = z4;
         if (wave == 0) reinterpret_cast<int2 *>(smem + C::OFF_PIV)[lane] = pv_mine;
+        if (GEN && tid < 4) reinterpret_cast<uint32_t *>(smem + C::OFF_RM)[tid] = 0u;
     }
     __syncthreads();
     {
@@ -359,12 +360,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                     const uint32_t a = alignb(hi[k], lo[k], sh);
                     const uint32_t m = (j == CD - 1) ? LASTM : 0xffffffffu;
                     *reinterpret_cast<uint32_t *>(CH + CH0 + CP * r + 4 * j) = (a ^ 0x80808080u) & m;
-                    if (NULLS) {
-                        const uint32_t s0 = (a & 0xffu) * (a & 0xffu), s1 = ((a >> 8) & 0xffu) * ((a >> 8) & 0xffu);
-                        const uint32_t s2 = ((a >> 16) & 0xffu) * ((a >> 16) & 0xffu), s3 = (a >> 24) * (a >> 24);
-                        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);
-                        *reinterpret_cast<uint32_t *>(CH + C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x05040100u) ^ 0x80808080u) & m;
-                        *reinterpret_cast<uint32_t *>(CH + 2 * C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x07060302u) ^ 0x80808080u) & m;
+                    if (GEN && cn) {                          // a null pixel (DN 0) among the dword's chip pixels: flag the chip row
+                        const uint32_t nz = (((a & 0x7f7f7f7fu) + 0x7f7f7f7fu) | a) & 0x80808080u & m;
+                        if (nz != (0x80808080u & m)) atomicOr(reinterpret_cast<uint32_t *>(smem + C::OFF_RM) + (r >> 5), 1u << (r & 31));
                     }
                 }
             }
@@ -384,53 +382,84 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     //      Software-pipelined by hand: the LDS reads of chip row r + 1 are in flight while row r's MFMAs issue (left to the compiler,
     //      every row waited for its own reads: one LDS latency per row).  No branch inside the loop: with conditional reads the
     //      compiler's wait counts assume the shorter queue; an odd chip is followed by an all-zero row, whose products add nothing.
-    v4i acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accz[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, accl[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acch[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    (void)accz; (void)accl; (void)acch;
+    const v4i zero4 = {0, 0, 0, 0};
+    // accumulators (two 16 x 16 tiles each): sum a'b'; general form, window nulls zb = [b == 0]: sum zb a', sum zb (a^2 & 255)', sum zb (a^2 >> 8)';
+    // chip nulls za = [a == 0]: sum b' za, sum (b^2 & 255)' za, sum (b^2 >> 8)' za, and sum zb za
+    v4i acc[2] = {zero4, zero4}, accz[2] = {zero4, zero4}, accl[2] = {zero4, zero4}, acch[2] = {zero4, zero4};
+    v4i accy[2] = {zero4, zero4}, accyl[2] = {zero4, zero4}, accyh[2] = {zero4, zero4}, acczz[2] = {zero4, zero4};
+    (void)accz; (void)accl; (void)acch; (void)accy; (void)accyl; (void)accyh; (void)acczz;
     {
-        struct RowOps { v4i a[2][KCW]; uint32_t d[C::NPL][KCW][5]; };
+        // general form: which chip rows hold nulls (their Toeplitz rows are the only ones the chip-null correlations need)
+        uint32_t rm0 = 0, rm1 = 0, rm2 = 0;
+        if (GEN && cn) {
+            const uint32_t *rmp = reinterpret_cast<const uint32_t *>(smem + C::OFF_RM);
+            rm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rmp[0]); rm1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rmp[1]);
+            rm2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rmp[2]);
+        }
+        auto row_has_null = [&](int r) __attribute__((always_inline)) -> bool {
+            const uint32_t w = r < 32 ? rm0 : (r < 64 ? rm1 : rm2);
+            return ((w >> (r & 31)) & 1u) != 0u;
+        };
+        v4i bmk[KCW];                                      // valid-byte masks of this lane's B operand (general form)
+        if (GEN) {
+#pragma unroll
+            for (int c = 0; c < KCW; c++) bmk[c] = *reinterpret_cast<const v4i *>(&kBands<CW, KCW, KCV>.bm[c][lane][0]);
+        }
+        struct RowOps { v4i a[2][KCW]; uint32_t d[KCW][5]; };
         auto issue = [&](int r, RowOps &o) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int c = 0; c < KCW; c++) o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
 #pragma unroll
-            for (int pl = 0; pl < C::NPL; pl++)
+            for (int c = 0; c < KCW; c++) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + CP * r + 64 * c);
 #pragma unroll
-                for (int c = 0; c < KCW; c++) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r + 64 * c);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) o.d[pl][c][k] = q[k];
-                }
+                for (int k = 0; k < 5; k++) o.d[c][k] = q[k];
+            }
         };
-        auto shifted = [&](const uint32_t (&d)[KCW][5], v4i (&b)[KCW]) __attribute__((always_inline)) {
+        auto consume = [&](const RowOps &o, int r) __attribute__((always_inline)) {
+            v4i b[KCW];
 #pragma unroll
             for (int c = 0; c < KCW; c++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[c][k + 1], d[c][k], bsh);
-        };
-        auto consume = [&](const RowOps &o) __attribute__((always_inline)) {
-            v4i b[KCW];
-            shifted(o.d[0], b);
+                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(o.d[c][k + 1], o.d[c][k], bsh);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int c = 0; c < KCW; c++) acc[m] = mfma(o.a[m][c], b[c], acc[m]);
-            if constexpr (NULLS) {
-                v4i z[2][KCW];
+            if constexpr (GEN) {
+                const bool cnrow = cn && row_has_null(r);
+                if (wn && r < CW) {                            // (not the all-zero row behind an odd chip: squared, its a' = 0 bytes would read as pixels of 128)
+                    // the byte planes of a^2 from the B operand itself (its padding bytes masked back to 0)
+                    v4i blo[KCW], bhi[KCW];
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                    for (int c = 0; c < KCW; c++) {
+                        squares(b[c], blo[c], bhi[c]);
 #pragma unroll
-                    for (int c = 0; c < KCW; c++) { z[m][c] = nullbytes(o.a[m][c]); accz[m] = mfma(z[m][c], b[c], accz[m]); }
-                shifted(o.d[1], b);
+                        for (int k = 0; k < 4; k++) { blo[c][k] &= bmk[c][k]; bhi[c][k] &= bmk[c][k]; }
+                    }
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                    for (int m = 0; m < 2; m++)
 #pragma unroll
-                    for (int c = 0; c < KCW; c++) accl[m] = mfma(z[m][c], b[c], accl[m]);
-                shifted(o.d[2], b);
+                        for (int c = 0; c < KCW; c++) {
+                            const v4i z = nullbytes(o.a[m][c]);
+                            accz[m] = mfma(z, b[c], accz[m]); accl[m] = mfma(z, blo[c], accl[m]); acch[m] = mfma(z, bhi[c], acch[m]);
+                        }
+                }
+                if (cnrow) {
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                    for (int c = 0; c < KCW; c++) {
+                        const v4i za = nullbytes(b[c]);            // (a padding byte is 0x00, a null chip pixel 0x80: no mask needed)
 #pragma unroll
-                    for (int c = 0; c < KCW; c++) acch[m] = mfma(z[m][c], b[c], acch[m]);
+                        for (int m = 0; m < 2; m++) {
+                            v4i lo, hi;
+                            squares(o.a[m][c], lo, hi);
+                            accy[m] = mfma(o.a[m][c], za, accy[m]); accyl[m] = mfma(lo, za, accyl[m]); accyh[m] = mfma(hi, za, accyh[m]);
+                            if (wn) acczz[m] = mfma(nullbytes(o.a[m][c]), za, acczz[m]);
+                        }
+                    }
+                }
             }
         };
         RowOps o0, o1;
@@ -439,11 +468,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         for (int r = 0; r < C::CWE; r += 2) {
             issue(r + 1, o1);
             __builtin_amdgcn_sched_barrier(0);
-            consume(o0);
+            consume(o0, r);
             __builtin_amdgcn_sched_barrier(0);
             issue(r + 2 < C::CWE ? r + 2 : r + 1, o0);          // (the last trip re-reads a row: nothing consumes it)
             __builtin_amdgcn_sched_barrier(0);
-            consume(o1);
+            consume(o1, r + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -463,7 +492,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
 #pragma unroll
             for (int c = 0; c < KCW; c++) a[c] = *reinterpret_cast<const v4i *>(arow + 16 * t * PW + 64 * c);
         };
-        const v4i zero4 = {0, 0, 0, 0};
         {   // sum b (and the null count)
             v4i p0[KCV], p1[KCV], pz[KCV];
 #pragma unroll
@@ -478,7 +506,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
 #pragma unroll
                     for (int i = 0; i < 4; i++) R[i] += 128 * CW;
                     planes2(R, q0, q1);
-                    if (NULLS) {
+                    if (GEN && wn) {
                         v4i Z = zero4;
 #pragma unroll
                         for (int c = 0; c < KCW; c++) Z = mfma(nullbytes(a[c]), hb[c], Z);
@@ -494,7 +522,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                 for (int c = 0; c < KCV; c++) {
                     const v4i vb = *reinterpret_cast<const v4i *>(&bd.vb[m][c][lane][0]);
                     v0 = mfma(vb, p0[c], v0); v1 = mfma(vb, p1[c], v1);
-                    if (NULLS) boxz[m] = mfma(vb, pz[c], boxz[m]);
+                    if (GEN && wn) boxz[m] = mfma(vb, pz[c], boxz[m]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i++) boxb[m][i] = (v0[i] + 128 * CW) + 256 * (v1[i] + 128 * CW);
@@ -554,24 +582,32 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         uint32_t SXo = SX, SXXo = SXX;
         // (opaque here: left alone, the compiler forms the f64 constants below in the header and carries twelve registers through every phase)
         asm volatile("" : "+s"(cS), "+s"(cSS), "+s"(rS), "+s"(rSS), "+s"(SXo), "+s"(SXXo));
-        const bool colT4 = !NULLS && cx == csx - 2;
-        const int rT4 = NULLS ? -1 : csy - 2 - ty0;         // tile row of the cells that reach the never-written last row
-        // (n, sx, va) of this lane's cells: off / on the T4 row
-        double dn0, dsx0, va0, dn1, dsx1, va1;
-        {
-            const int n0 = NPX - (colT4 ? CW : 0), sx0 = (int)SXo - (colT4 ? (int)cS : 0), sxx0 = (int)SXXo - (colT4 ? (int)cSS : 0);
-            const int n1 = n0 - CW + (colT4 ? 1 : 0), sx1 = sx0 - (int)rS + (colT4 ? (int)corner : 0), sxx1 = sxx0 - (int)rSS + (colT4 ? (int)(corner * corner) : 0);
+        // T4 in closed form unless the window's own nulls are correlated anyway (wn): the never-written column / row take the chip's
+        // last column / row out of n, sx, sxx -- its non-null pixels, with a chip that holds nulls
+        const bool colT4 = !wn && cx == csx - 2;
+        const int rT4 = wn ? -1 : csy - 2 - ty0;            // tile row of the cells that reach the never-written last row
+        const int Na = chip_nulls;
+        const int cN = (int)(colQ >> kSatNullShift8), rN = (int)(rowQ >> kSatNullShift8), kN = corner == 0u ? 1 : 0;   // nulls of the chip's last column / row / corner pixel
+        // (n, sx, sxx) of this lane's cells before the window's own nulls: off / on the T4 row
+        const int n0 = NPX - Na - (colT4 ? CW - cN : 0), sx0 = (int)SXo - (colT4 ? (int)cS : 0), sxx0 = (int)SXXo - (colT4 ? (int)cSS : 0);
+        const int n1 = n0 - (CW - rN) + (colT4 ? 1 - kN : 0), sx1 = sx0 - (int)rS + (colT4 ? (int)corner : 0), sxx1 = sxx0 - (int)rSS + (colT4 ? (int)(corner * corner) : 0);
+        double dn0 = 0, dsx0 = 0, va0 = 0, dn1 = 0, dsx1 = 0, va1 = 0;
+        if (!wn) {
             dn0 = (double)n0; dsx0 = (double)sx0; va0 = dn0 * (double)sxx0 - dsx0 * dsx0;
             dn1 = (double)n1; dsx1 = (double)sx1; va1 = dn1 * (double)sxx1 - dsx1 * dsx1;
         }
         auto cell_in = [&](int m, int i, double &dn, double &dsx, double &va, int &sxy, int &sy, int &syy) __attribute__((always_inline)) {
             const int ry = 16 * m + 4 * h + i;
             sy = boxb[m][i]; syy = boxq[m][i];
-            sxy = acc[m][i] + 128 * ((int)SXo + sy) - 16384 * NPX;
-            if (NULLS) {
+            sxy = acc[m][i] + 128 * ((int)SXo + sy) - 16384 * NPX;          // (over all chip positions: a null is a zero factor)
+            if (GEN && cn) {                                   // chip nulls take window pixels out of sy, syy
+                sy -= accy[m][i] + 128 * Na;
+                syy -= (accyl[m][i] + 128 * Na) + 256 * (accyh[m][i] + 128 * Na);
+            }
+            if (GEN && wn) {                                   // window nulls (T4 among them) take chip pixels out of n, sx, sxx
                 const int nz = boxz[m][i];
                 const int ca = accz[m][i] + 128 * nz, caa = (accl[m][i] + 128 * nz) + 256 * (acch[m][i] + 128 * nz);
-                dn = (double)(NPX - nz); dsx = (double)((int)SXo - ca);
+                dn = (double)(NPX - Na - nz + (cn ? acczz[m][i] : 0)); dsx = (double)((int)SXo - ca);
                 va = dn * (double)((int)SXXo - caa) - dsx * dsx;
             } else {
                 const bool rowT4 = ry == rT4;
@@ -815,7 +851,7 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
             free(hf);
         }
         fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f products %.0f box sums %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
-                C::OCW, C::NULLS ? "nulls" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
+                C::OCW, C::GEN ? "general" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
     }
     return hipGetLastError();
 }
@@ -831,21 +867,21 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half)
     return ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40;
 }
 
-template <bool NULLS>
+template <bool GEN>
 static hipError_t launch_form(const MatchU8Args &a, hipStream_t stream)
 {
     switch (a.ocw) {
-    case 7: return mx::launch_one<mx::Cfg<7, NULLS>>(a, stream);
-    case 15: return mx::launch_one<mx::Cfg<15, NULLS>>(a, stream);
-    case 16: return mx::launch_one<mx::Cfg<16, NULLS>>(a, stream);
-    case 30: return mx::launch_one<mx::Cfg<30, NULLS>>(a, stream);
-    case 32: return mx::launch_one<mx::Cfg<32, NULLS>>(a, stream);
-    case 40: return mx::launch_one<mx::Cfg<40, NULLS>>(a, stream);
+    case 7: return mx::launch_one<mx::Cfg<7, GEN>>(a, stream);
+    case 15: return mx::launch_one<mx::Cfg<15, GEN>>(a, stream);
+    case 16: return mx::launch_one<mx::Cfg<16, GEN>>(a, stream);
+    case 30: return mx::launch_one<mx::Cfg<30, GEN>>(a, stream);
+    case 32: return mx::launch_one<mx::Cfg<32, GEN>>(a, stream);
+    case 40: return mx::launch_one<mx::Cfg<40, GEN>>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-// Two launches: the clean form over all points (or the caller's list), the NULLS form over the points it flagged.  Points neither
+// Two launches: the clean form over all points (or the caller's list), the general form over the points it flagged.  Points neither
 // takes carry kMxRest in mx_flags afterwards.
 hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {

@@ -791,6 +791,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
         satz_win = reinterpret_cast<const uint32_t *>(p.swap ? p.satz0 : p.satz1);
         const int wc = 2 * pt.dx2 + (full_win ? 1 : 0), wr = 2 * pt.dy2 + (full_win ? 1 : 0);          // the written area (:869-886)
         if constexpr (kSatZ) win_nulls = (int)sat_box(satz_win, p.sat_ws, wu0, wv0, wc, wr);
+        else if constexpr (std::is_same<SatT, unsigned long long>::value && !P::SATZ && P::BPP == 1)
+            win_nulls = sat_nulls_u8(reinterpret_cast<const unsigned long long *>(sat_win), p.sat_ws, wu0, wv0, wc, wr, lane);   // exact for any window size (one packed query is not, beyond 8,224 px)
         else win_nulls = P::sat_nulls(sat_box(sat_win, p.sat_ws, wu0, wv0, wc, wr));
         if constexpr (kSatChip) {
             chipQ = sat_box(sat_chip, p.sat_ws, u0 - OCW + PAD, v0 - OCW + PAD, CW, CW);

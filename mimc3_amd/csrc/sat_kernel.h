@@ -48,4 +48,23 @@ __device__ __forceinline__ T sat_box(const T *__restrict__ S, int Ws, int x, int
     return r1[w] - r0[w] - r1[0] + r0[0];
 }
 
+// Null count of a w x h box of a u8 plane from its packed table, exact for ANY box size.  The packed fields of one query are exact up to
+// 8,224 pixels (sum b < 2^21; beyond that the field above takes a carry and the null count comes back off by it -- a window of
+// 16,384 - carry nulls would read as null-free).  Larger boxes are cut into sub-boxes of at most 64 x 64 pixels, one per lane, and the
+// counts are summed over the wave.  Wave-uniform arguments; every lane gets the result.
+__device__ __forceinline__ int sat_nulls_u8(const unsigned long long *__restrict__ S, int Ws, int x, int y, int w, int h, int lane)
+{
+    if (w * h <= 8224) return (int)(sat_box(S, Ws, x, y, w, h) >> kSatNullShift8);
+    const int nx = (w + 63) >> 6, ny = (h + 63) >> 6;
+    int cnt = 0;
+    for (int t = lane; t < nx * ny; t += 64) {
+        const int j = t / nx, i = t - j * nx;
+        const int w0 = w - 64 * i < 64 ? w - 64 * i : 64, h0 = h - 64 * j < 64 ? h - 64 * j : 64;
+        cnt += (int)(sat_box(S, Ws, x + 64 * i, y + 64 * j, w0, h0) >> kSatNullShift8);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    return cnt;
+}
+
 }  // namespace mimc3

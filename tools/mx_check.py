@@ -46,9 +46,17 @@ def run_case(name, c, ocws, reps=3):
                           "diff_forward": nf, "diff_swapped": ns, "first_bad": wf + ws,
                           "ms_u8px": round(res["u8px"][2], 3), "ms_auto": round(res["auto"][2], 3),
                           "invalid": int(np.isnan(res["auto"][0][:, 0]).sum())}), flush=True)
-        if nf:
-            g = wf[0]
-            print("   point", g, "auto", res["auto"][0][g].tolist(), "u8px", res["u8px"][0][g].tolist(), flush=True)
+        if nf and os.environ.get("MX_CHECK_VERBOSE"):
+            for g in wf[:6]:
+                u0, v0 = int(c.xyuvav[g, 2]), int(c.xyuvav[g, 3])
+                chip = c.i0[v0 - ocw:v0 + ocw + 1, u0 - ocw:u0 + ocw + 1]
+                k0, k1 = int(off[g]), int(off[g + 1])
+                lu, lv = int(uv[k1 - 1, 0]), int(uv[k1 - 1, 1])
+                dx2, dy2 = abs(lu) + ocw + 2, abs(lv) + ocw + 2
+                wu, wv = u0 + int(c.offset[0]) - dx2, v0 + int(c.offset[1]) - dy2
+                win = c.i1[max(wv, 0):wv + 2 * dy2, max(wu, 0):wu + 2 * dx2]
+                print("   point", g, "npiv", k1 - k0, "chip nulls", int((chip == 0).sum()), "chip null rows", int((chip == 0).any(axis=1).sum()),
+                      "window nulls", int((win == 0).sum()), "auto", res["auto"][0][g].tolist(), "u8px", res["u8px"][0][g].tolist(), flush=True)
 
 
 def main():
