@@ -92,8 +92,13 @@ struct Cfg {
     static constexpr int VP = 33;                       // pitch (words) of the NCC surface
     static constexpr int LDS_W = (16 * NTR + 1) * PW;   // (+ the row the product loop's zero chip row reads)
     static constexpr int LDS_VAL = 4 * 32 * VP;
-    static constexpr int OFF_CH = ((LDS_W > LDS_VAL ? LDS_W : LDS_VAL) + 15) & ~15;      // the surface reuses the tile's bytes once the sums are in registers
-    static constexpr int OFF_VIS = OFF_CH + CHB;
+    static constexpr int NPL = GEN_ ? 3 : 1;            // chip planes: a', and in the general form (a^2 & 255)', (a^2 >> 8)' (the B operands of the window-null corrections)
+    // general form, small chips: the window's null plane (0x80 where b == 0) staged next to the tile, so that the A operand of the window-null
+    // correlations is a load; the big chips, short of LDS, form it from the tile's bytes in registers (3 instructions per dword)
+    static constexpr bool ZPL = GEN_ && OCW_ <= 16;
+    static constexpr int OFF_Z = ((LDS_W > LDS_VAL ? LDS_W : LDS_VAL) + 15) & ~15;       // the surface reuses the tile's bytes once the sums are in registers
+    static constexpr int OFF_CH = OFF_Z + (ZPL ? LDS_W : 0);
+    static constexpr int OFF_VIS = OFF_CH + NPL * CHB;
     static constexpr int OFF_PIV = OFF_VIS + 128;      // the pivots' starts, parked for wave 0's climbs
     static constexpr int OFF_RM = OFF_PIV + 512;       // general form: bit r = chip row r holds a null pixel
     static constexpr int LDS = OFF_RM + 16;
@@ -148,6 +153,16 @@ __device__ __forceinline__ void squares(const v4i &a, v4i &lo, v4i &hi)
         lo[k] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
         hi[k] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
     }
+}
+// 0x80 (the signed byte -128) in every byte of an operand that is a null pixel (its signed byte is 0x80, i.e. the pixel 0; Toeplitz padding
+// is 0x00): three instructions per dword.  A correlation with this plane is -128 times the correlation with the 0 / 1 null mask -- exactly
+__device__ __forceinline__ uint32_t null80(uint32_t x) { return x & ~((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) & 0x80808080u; }
+__device__ __forceinline__ v4i null80v(const v4i &a)
+{
+    v4i z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) z[k] = (int)null80((uint32_t)a[k]);
+    return z;
 }
 // 1 in every byte of the A operand that is a null pixel (b == 0, i.e. b' == 0x80)
 __device__ __forceinline__ v4i nullbytes(const v4i &a)
@@ -317,6 +332,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                     w.z = alignb(d[k][3], d[k][2], sh) ^ 0x80808080u;
                     w.w = alignb(d[k][4], d[k][3], sh) ^ 0x80808080u;
                     *reinterpret_cast<uint4 *>(WT + y * PW + 16 * q) = w;
+                    if (C::ZPL && wn) *reinterpret_cast<uint4 *>(smem + C::OFF_Z + y * PW + 16 * q) = make_uint4(null80(w.x), null80(w.y), null80(w.z), null80(w.w));
                 }
             }
         }
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     // ---- chip planes: zeros, then CW rows of (a ^ 0x80) [and of the two byte planes of a^2] -------------------------------
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < C::CHB / 16; i += NT) reinterpret_cast<uint4 *>(CH)[i] = z4;
+        for (int i = tid; i < (C::NPL * C::CHB) / 16; i += NT) reinterpret_cast<uint4 *>(CH)[i] = z4;
         if (wave == 0) reinterpret_cast<int2 *>(smem + C::OFF_PIV)[lane] = pv_mine;
         if (GEN && tid < 4) reinterpret_cast<uint32_t *>(smem + C::OFF_RM)[tid] = 0u;
     }
@@ -333,8 +349,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         // T4: the search area's last column and last row are never written (:869-886): nulls.  (What lies beyond them inside the tile
         // only reaches cells no climb can touch.)
         const int zx = Dx2 - 1 - tx0, zy = Dy2 - 1 - ty0;
-        if (zx < C::SW) for (int y = tid; y < C::KW; y += NT) WT[y * PW + zx] = 0x80;
-        if (zy < C::KW) for (int x = tid; x < C::SW / 4; x += NT) *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
+        if (zx < C::SW) for (int y = tid; y < C::KW; y += NT) { WT[y * PW + zx] = 0x80; if (C::ZPL && wn) smem[C::OFF_Z + y * PW + zx] = 0x80; }
+        if (zy < C::KW) for (int x = tid; x < C::SW / 4; x += NT) {
+            *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
+            if (C::ZPL && wn) *reinterpret_cast<uint32_t *>(smem + C::OFF_Z + zy * PW + 4 * x) = 0x80808080u;
+        }
         const int sh = cu0 & 3;
         const uint32_t *gb = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 - sh));
         const int gp = Wp >> 2;
@@ -360,6 +379,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                     const uint32_t a = alignb(hi[k], lo[k], sh);
                     const uint32_t m = (j == CD - 1) ? LASTM : 0xffffffffu;
                     *reinterpret_cast<uint32_t *>(CH + CH0 + CP * r + 4 * j) = (a ^ 0x80808080u) & m;
+                    if (GEN && wn) {                          // the byte planes of a^2
+                        const uint32_t s0 = (a & 0xffu) * (a & 0xffu), s1 = ((a >> 8) & 0xffu) * ((a >> 8) & 0xffu);
+                        const uint32_t s2 = ((a >> 16) & 0xffu) * ((a >> 16) & 0xffu), s3 = (a >> 24) * (a >> 24);
+                        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);
+                        *reinterpret_cast<uint32_t *>(CH + C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x05040100u) ^ 0x80808080u) & m;
+                        *reinterpret_cast<uint32_t *>(CH + 2 * C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x07060302u) ^ 0x80808080u) & m;
+                    }
                     if (GEN && cn) {                          // a null pixel (DN 0) among the dword's chip pixels: flag the chip row
                         const uint32_t nz = (((a & 0x7f7f7f7fu) + 0x7f7f7f7fu) | a) & 0x80808080u & m;
                         if (nz != (0x80808080u & m)) atomicOr(reinterpret_cast<uint32_t *>(smem + C::OFF_RM) + (r >> 5), 1u << (r & 31));
@@ -400,63 +426,64 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             const uint32_t w = r < 32 ? rm0 : (r < 64 ? rm1 : rm2);
             return ((w >> (r & 31)) & 1u) != 0u;
         };
-        v4i bmk[KCW];                                      // valid-byte masks of this lane's B operand (general form)
-        if (GEN) {
-#pragma unroll
-            for (int c = 0; c < KCW; c++) bmk[c] = *reinterpret_cast<const v4i *>(&kBands<CW, KCW, KCV>.bm[c][lane][0]);
-        }
-        struct RowOps { v4i a[2][KCW]; uint32_t d[KCW][5]; };
+        const unsigned char *zrow = smem + C::OFF_Z + (arow - WT);         // the null plane under the lane's A operand (ZPL)
+        (void)zrow;
+        struct RowOps { v4i a[2][KCW]; v4i az[C::ZPL ? 2 : 1][KCW]; uint32_t d[C::NPL][KCW][5]; };
         auto issue = [&](int r, RowOps &o) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int c = 0; c < KCW; c++) o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
+                for (int c = 0; c < KCW; c++) {
+                    o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
+                    if constexpr (C::ZPL) o.az[m][c] = *reinterpret_cast<const v4i *>(zrow + (r + 16 * m) * PW + 64 * c);
+                }
 #pragma unroll
-            for (int c = 0; c < KCW; c++) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + CP * r + 64 * c);
+            for (int pl = 0; pl < C::NPL; pl++)
 #pragma unroll
-                for (int k = 0; k < 5; k++) o.d[c][k] = q[k];
-            }
+                for (int c = 0; c < KCW; c++) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r + 64 * c);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) o.d[pl][c][k] = q[k];
+                }
         };
-        auto consume = [&](const RowOps &o, int r) __attribute__((always_inline)) {
-            v4i b[KCW];
+        auto shifted = [&](const uint32_t (&d)[KCW][5], v4i (&b)[KCW]) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < KCW; c++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(o.d[c][k + 1], o.d[c][k], bsh);
+                for (int k = 0; k < 4; k++) b[c][k] = (int)alignb(d[c][k + 1], d[c][k], bsh);
+        };
+        // (the null-plane operands are 0x80 = -128 per null: their correlations come out times -128, their product times 16384)
+        auto consume = [&](const RowOps &o, int r) __attribute__((always_inline)) {
+            v4i b[KCW];
+            shifted(o.d[0], b);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int c = 0; c < KCW; c++) acc[m] = mfma(o.a[m][c], b[c], acc[m]);
             if constexpr (GEN) {
                 const bool cnrow = cn && row_has_null(r);
-                if (wn && r < CW) {                            // (not the all-zero row behind an odd chip: squared, its a' = 0 bytes would read as pixels of 128)
-                    // the byte planes of a^2 from the B operand itself (its padding bytes masked back to 0)
+                v4i z[2][KCW];
+                if (wn) {
                     v4i blo[KCW], bhi[KCW];
-#pragma unroll
-                    for (int c = 0; c < KCW; c++) {
-                        squares(b[c], blo[c], bhi[c]);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { blo[c][k] &= bmk[c][k]; bhi[c][k] &= bmk[c][k]; }
-                    }
+                    shifted(o.d[1], blo); shifted(o.d[2], bhi);
 #pragma unroll
                     for (int m = 0; m < 2; m++)
 #pragma unroll
                         for (int c = 0; c < KCW; c++) {
-                            const v4i z = nullbytes(o.a[m][c]);
-                            accz[m] = mfma(z, b[c], accz[m]); accl[m] = mfma(z, blo[c], accl[m]); acch[m] = mfma(z, bhi[c], acch[m]);
+                            if constexpr (C::ZPL) z[m][c] = o.az[m][c]; else z[m][c] = null80v(o.a[m][c]);
+                            accz[m] = mfma(z[m][c], b[c], accz[m]); accl[m] = mfma(z[m][c], blo[c], accl[m]); acch[m] = mfma(z[m][c], bhi[c], acch[m]);
                         }
                 }
                 if (cnrow) {
 #pragma unroll
                     for (int c = 0; c < KCW; c++) {
-                        const v4i za = nullbytes(b[c]);            // (a padding byte is 0x00, a null chip pixel 0x80: no mask needed)
+                        const v4i za = null80v(b[c]);              // (a padding byte is 0x00, a null chip pixel 0x80)
 #pragma unroll
                         for (int m = 0; m < 2; m++) {
                             v4i lo, hi;
                             squares(o.a[m][c], lo, hi);
                             accy[m] = mfma(o.a[m][c], za, accy[m]); accyl[m] = mfma(lo, za, accyl[m]); accyh[m] = mfma(hi, za, accyh[m]);
-                            if (wn) acczz[m] = mfma(nullbytes(o.a[m][c]), za, acczz[m]);
+                            if (wn) acczz[m] = mfma(z[m][c], za, acczz[m]);
                         }
                     }
                 }
@@ -506,10 +533,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
 #pragma unroll
                     for (int i = 0; i < 4; i++) R[i] += 128 * CW;
                     planes2(R, q0, q1);
-                    if (GEN && wn) {
+                    if (GEN && wn) {                          // the row counts of the nulls (the null plane is -128 per null)
                         v4i Z = zero4;
 #pragma unroll
-                        for (int c = 0; c < KCW; c++) Z = mfma(nullbytes(a[c]), hb[c], Z);
+                        for (int c = 0; c < KCW; c++) {
+                            v4i zc;
+                            if constexpr (C::ZPL) zc = *reinterpret_cast<const v4i *>(smem + C::OFF_Z + (arow - WT) + 16 * t * PW + 64 * c);
+                            else zc = null80v(a[c]);
+                            Z = mfma(zc, hb[c], Z);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) Z[i] = (-Z[i]) >> 7;
                         qz = planes1(Z);
                     }
                 }
@@ -601,13 +635,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             sy = boxb[m][i]; syy = boxq[m][i];
             sxy = acc[m][i] + 128 * ((int)SXo + sy) - 16384 * NPX;          // (over all chip positions: a null is a zero factor)
             if (GEN && cn) {                                   // chip nulls take window pixels out of sy, syy
-                sy -= accy[m][i] + 128 * Na;
-                syy -= (accyl[m][i] + 128 * Na) + 256 * (accyh[m][i] + 128 * Na);
+                sy -= ((-accy[m][i]) >> 7) + 128 * Na;
+                syy -= (((-accyl[m][i]) >> 7) + 128 * Na) + 256 * (((-accyh[m][i]) >> 7) + 128 * Na);
             }
             if (GEN && wn) {                                   // window nulls (T4 among them) take chip pixels out of n, sx, sxx
                 const int nz = boxz[m][i];
-                const int ca = accz[m][i] + 128 * nz, caa = (accl[m][i] + 128 * nz) + 256 * (acch[m][i] + 128 * nz);
-                dn = (double)(NPX - Na - nz + (cn ? acczz[m][i] : 0)); dsx = (double)((int)SXo - ca);
+                const int ca = ((-accz[m][i]) >> 7) + 128 * nz, caa = (((-accl[m][i]) >> 7) + 128 * nz) + 256 * (((-acch[m][i]) >> 7) + 128 * nz);
+                dn = (double)(NPX - Na - nz + (cn ? (acczz[m][i] >> 14) : 0)); dsx = (double)((int)SXo - ca);
                 va = dn * (double)((int)SXXo - caa) - dsx * dsx;
             } else {
                 const bool rowT4 = ry == rT4;
