@@ -60,6 +60,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     // form to its window-null form, kMxRest = neither form takes the point (plain stores: a shared list counter serialises ~100,000
     // same-address atomics per launch, measured 1.0 ms)
     uint8_t *mx_flags;
+    int32_t mx_gen_on;              // 0: the clean form hands points with nulls straight to the register-tiled kernel (kMxRest)
     // flag mode of every kernel of the family: workgroup b handles point b only if point_flags[b] == flag_value
     const uint8_t *point_flags;
     int32_t flag_value;

@@ -247,25 +247,46 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     const int64_t pbeg = p.piv_off[gidx];
     const int npiv = (int)(p.piv_off[gidx + 1] - pbeg);
     const int32_t *pv_g = p.piv_uv + 2 * pbeg;
-    const int lu = pv_g[2 * (npiv - 1)], lv = pv_g[2 * (npiv - 1) + 1];
+    // Everything the header needs from memory beyond (u, v) and the pivot range is issued together -- the last pivot, the twelve table
+    // corners of the three chip-side queries (one per lane), the chip's corner pixel, this lane's pivot -- and only then waited for:
+    // one memory round trip instead of one per query (the values are wave-uniform, but the kernel stores to global memory, so the
+    // compiler loads them through the vector path and every readfirstlane is a wait).
+    const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;                       // plane position of chip pixel (0, 0)
+    typedef unsigned long long SatT;
+    const SatT *sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
+    const SatT *sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
+    const int2 lastpv = *reinterpret_cast<const int2 *>(pv_g + 2 * (npiv - 1));
+    SatT satv = 0;
+    {   // lane 4 q + c: corner c of query q (0: the chip, 1: its last column, 2: its last row)
+        const int q = (lane >> 2) & 3, c = lane & 3;
+        const int bx = cu0 + (q == 1 ? CW - 1 : 0), by = cv0 + (q == 2 ? CW - 1 : 0), bw = q == 1 ? 1 : CW, bh = q == 2 ? 1 : CW;
+        if (lane < 12) satv = sat_chip[(size_t)(by + ((c & 2) ? bh : 0)) * p.sat_ws + bx + ((c & 1) ? bw : 0)];
+    }
+    const uint32_t cornerv = chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1];
+    // the pivots (lane k of wave 0 = pivot k in the climbs): parked in LDS until the surface is there
+    int2 pv_mine = make_int2(0, 0);
+    if (wave == 0 && lane < npiv && npiv <= 64) pv_mine = *reinterpret_cast<const int2 *>(pv_g + 2 * lane);
+    // ... and the first batch of the chip's pixels (aligned dwords of its rows; written to LDS once the tile is on its way)
+    constexpr int CD = C::CD, CTASK = CW * CD, CNIT = (CTASK + NT - 1) / NT, CKB = CNIT < 5 ? CNIT : 5;
+    const int csh = cu0 & 3;
+    const uint32_t *cgb = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 - csh));
+    uint32_t clo[CKB], chi[CKB];
+    auto chip_loads = [&](int it0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < CKB; k++) {
+            const int t = tid + NT * (it0 + k);
+            const int r = t / CD, j = t - CD * r;
+            const bool on = (it0 + k < CNIT) && t < CTASK;
+            const uint32_t *g = cgb + (size_t)(on ? r : 0) * (Wp >> 2) + (on ? j : 0);
+            clo[k] = g[0]; chi[k] = g[1];
+        }
+    };
+    chip_loads(0);
+    const int lu = __builtin_amdgcn_readfirstlane(lastpv.x), lv = __builtin_amdgcn_readfirstlane(lastpv.y);
     const int dx2 = (lu < 0 ? -lu : lu) + OCW + 2, dy2 = (lv < 0 ? -lv : lv) + OCW + 2;
     const int Dx2 = 2 * dx2 + 1, Dy2 = 2 * dy2 + 1;
     const int csx = Dx2 - 2 * OCW + 1, csy = Dy2 - 2 * OCW + 1;          // compact cells; a climb touches [1, cs - 2]
     const int wu0 = u0 + p.off_u - dx2 + PAD, wv0 = v0 + p.off_v - dy2 + PAD;   // plane position of window pixel (0, 0)
-    const int cu0 = u0 - OCW + PAD, cv0 = v0 - OCW + PAD;                       // ... of chip pixel (0, 0)
-    typedef unsigned long long SatT;
-    const SatT *sat_chip = reinterpret_cast<const SatT *>(p.swap ? p.sat1 : p.sat0);
-    const SatT *sat_win = reinterpret_cast<const SatT *>(p.swap ? p.sat0 : p.sat1);
-    // table queries: the chip's sums and null count, the null count of the window's written area (:869-886), and -- for the
-    // closed-form T4 terms of the clean form -- the chip's last column and last row
-    const SatT chipQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0, CW, CW));
-    const SatT colQ = uni64(sat_box(sat_chip, p.sat_ws, cu0 + CW - 1, cv0, 1, CW));
-    const SatT rowQ = uni64(sat_box(sat_chip, p.sat_ws, cu0, cv0 + CW - 1, CW, 1));
-    const uint32_t corner = (uint32_t)__builtin_amdgcn_readfirstlane((int)chip_pl[(size_t)(cv0 + CW - 1) * Wp + cu0 + CW - 1]);
-    // the pivots (lane k of wave 0 = pivot k in the climbs): fetched with the header's loads, parked in LDS until the surface is there
-    int2 pv_mine = make_int2(0, 0);
-    if (wave == 0 && lane < npiv && npiv <= 64) pv_mine = *reinterpret_cast<const int2 *>(pv_g + 2 * lane);
-
     // ---- what this kernel takes -----------------------------------------------------------------------------------
     // the tile: all reachable cells if they fit, else centred on the pivots' starts (a scan that leaves it hands the point on)
     int tx0 = 1, ty0 = 1;
@@ -276,10 +297,39 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         if (csx - 2 > 32) { tx0 = min(max((lox + hix) / 2 - 15, 1), csx - 2 - 31); fits = fits && lox - 1 >= tx0 && hix + 1 <= tx0 + 31; }
         if (csy - 2 > 32) { ty0 = min(max((loy + hiy) / 2 - 15, 1), csy - 2 - 31); fits = fits && loy - 1 >= ty0 && hiy + 1 <= ty0 + 31; }
     }
+    // the null count of the window's written area (:869-886) and the first batch of the tile's pixels: issued now, read below
+    const int win_nulls_v = sat_nulls_u8(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2, lane);      // (exact for any window size)
+    constexpr int NSEG = C::SW / 16, TTASK = C::KW * NSEG;           // (tile rows >= KW and columns >= SW are only ever weighted 0: left as they are)
+    constexpr int TNIT = (TTASK + NT - 1) / NT, TKB = TNIT < 4 ? TNIT : 4;
+    const int tsh = (wu0 + tx0) & 3;
+    const uint32_t *tgb = reinterpret_cast<const uint32_t *>(win_pl + (size_t)(wv0 + ty0) * Wp + (wu0 + tx0 - tsh));
+    uint32_t td[TKB][5];
+    auto tile_loads = [&](int it0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < TKB; k++) {
+            const int t = tid + NT * (it0 + k);
+            const int y = t / NSEG, q = t - NSEG * y;
+            const bool on = (it0 + k < TNIT) && t < TTASK;
+            const uint32_t *g = tgb + (size_t)(on ? y : 0) * (Wp >> 2) + 4 * (on ? q : 0);
+#pragma unroll
+            for (int j = 0; j < 5; j++) td[k][j] = g[j];
+        }
+    };
+    tile_loads(0);
+    // the chip's sums and null count, and -- for the closed-form T4 terms -- those of its last column and last row
+    auto lane64 = [&](int l) __attribute__((always_inline)) -> SatT {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)satv, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(satv >> 32), l);
+        return ((SatT)hi << 32) | lo;
+    };
+    const SatT chipQ = lane64(3) - lane64(1) - lane64(2) + lane64(0);
+    const SatT colQ = lane64(7) - lane64(5) - lane64(6) + lane64(4);
+    const SatT rowQ = lane64(11) - lane64(9) - lane64(10) + lane64(8);
+    const uint32_t corner = (uint32_t)__builtin_amdgcn_readfirstlane((int)cornerv);
+
     const int chip_nulls = (int)(chipQ >> kSatNullShift8);
-    const int win_nulls = __builtin_amdgcn_readfirstlane(sat_nulls_u8(sat_win, p.sat_ws, wu0, wv0, 2 * dx2, 2 * dy2, lane));    // (exact for any window size)
+    const int win_nulls = __builtin_amdgcn_readfirstlane(win_nulls_v);
     if (npiv > 64 || !fits) { hand_on(kMxRest); return; }
-    if (!GEN && (win_nulls != 0 || chip_nulls != 0)) { hand_on(kMxNulls); return; }
+    if (!GEN && (win_nulls != 0 || chip_nulls != 0)) { hand_on(p.mx_gen_on ? kMxNulls : kMxRest); return; }
     // general form: wn = the written area of the window holds nulls (then the never-written last row / column are nulls like any other,
     // else they are applied in closed form as in the clean form); cn = the chip holds nulls
     const bool wn = GEN && win_nulls != 0, cn = GEN && chip_nulls != 0;
@@ -302,35 +352,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
 
     // ---- stage the tile: window pixels (tx0 + x, ty0 + y), x < SW, y < KW, as signed bytes b - 128 (both waves) ---------------
     {
-        const int gu = wu0 + tx0, gv = wv0 + ty0;
-        const int sh = gu & 3;
-        const uint32_t *gb = reinterpret_cast<const uint32_t *>(win_pl + (size_t)gv * Wp + (gu - sh));
-        const int gp = Wp >> 2;
-        constexpr int NSEG = C::SW / 16, NTASK = C::KW * NSEG;       // (rows >= KW and columns >= SW are only ever weighted 0: left as they are)
-        constexpr int NIT = (NTASK + NT - 1) / NT;
-        constexpr int KB = NIT < 4 ? NIT : 4;
 #pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += KB) {
-            uint32_t d[KB][5];
+        for (int it0 = 0; it0 < TNIT; it0 += TKB) {
+            if (it0 > 0) tile_loads(it0);
 #pragma unroll
-            for (int k = 0; k < KB; k++) {
+            for (int k = 0; k < TKB; k++) {
                 const int t = tid + NT * (it0 + k);
                 const int y = t / NSEG, q = t - NSEG * y;
-                const bool on = (it0 + k < NIT) && t < NTASK;
-                const uint32_t *g = gb + (size_t)(on ? y : 0) * gp + 4 * (on ? q : 0);
-#pragma unroll
-                for (int j = 0; j < 5; j++) d[k][j] = g[j];
-            }
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-                const int t = tid + NT * (it0 + k);
-                const int y = t / NSEG, q = t - NSEG * y;
-                if ((it0 + k < NIT) && t < NTASK) {
+                if ((it0 + k < TNIT) && t < TTASK) {
                     uint4 w;
-                    w.x = alignb(d[k][1], d[k][0], sh) ^ 0x80808080u;
-                    w.y = alignb(d[k][2], d[k][1], sh) ^ 0x80808080u;
-                    w.z = alignb(d[k][3], d[k][2], sh) ^ 0x80808080u;
-                    w.w = alignb(d[k][4], d[k][3], sh) ^ 0x80808080u;
+                    w.x = alignb(td[k][1], td[k][0], tsh) ^ 0x80808080u;
+                    w.y = alignb(td[k][2], td[k][1], tsh) ^ 0x80808080u;
+                    w.z = alignb(td[k][3], td[k][2], tsh) ^ 0x80808080u;
+                    w.w = alignb(td[k][4], td[k][3], tsh) ^ 0x80808080u;
                     *reinterpret_cast<uint4 *>(WT + y * PW + 16 * q) = w;
                     if (C::ZPL && wn) *reinterpret_cast<uint4 *>(smem + C::OFF_Z + y * PW + 16 * q) = make_uint4(null80(w.x), null80(w.y), null80(w.z), null80(w.w));
                 }
@@ -354,29 +388,16 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             *reinterpret_cast<uint32_t *>(WT + zy * PW + 4 * x) = 0x80808080u;
             if (C::ZPL && wn) *reinterpret_cast<uint32_t *>(smem + C::OFF_Z + zy * PW + 4 * x) = 0x80808080u;
         }
-        const int sh = cu0 & 3;
-        const uint32_t *gb = reinterpret_cast<const uint32_t *>(chip_pl + (size_t)cv0 * Wp + (cu0 - sh));
-        const int gp = Wp >> 2;
-        constexpr int CD = C::CD, NTASK = CW * CD, NIT = (NTASK + NT - 1) / NT;
-        constexpr int KB = NIT < 5 ? NIT : 5;
         constexpr uint32_t LASTM = C::LASTN >= 4 ? 0xffffffffu : ((1u << (8 * C::LASTN)) - 1u);
 #pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += KB) {
-            uint32_t lo[KB], hi[KB];
+        for (int it0 = 0; it0 < CNIT; it0 += CKB) {
+            if (it0 > 0) chip_loads(it0);
 #pragma unroll
-            for (int k = 0; k < KB; k++) {
+            for (int k = 0; k < CKB; k++) {
                 const int t = tid + NT * (it0 + k);
                 const int r = t / CD, j = t - CD * r;
-                const bool on = (it0 + k < NIT) && t < NTASK;
-                const uint32_t *g = gb + (size_t)(on ? r : 0) * gp + (on ? j : 0);
-                lo[k] = g[0]; hi[k] = g[1];
-            }
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-                const int t = tid + NT * (it0 + k);
-                const int r = t / CD, j = t - CD * r;
-                if ((it0 + k < NIT) && t < NTASK) {
-                    const uint32_t a = alignb(hi[k], lo[k], sh);
+                if ((it0 + k < CNIT) && t < CTASK) {
+                    const uint32_t a = alignb(chi[k], clo[k], csh);
                     const uint32_t m = (j == CD - 1) ? LASTM : 0xffffffffu;
                     *reinterpret_cast<uint32_t *>(CH + CH0 + CP * r + 4 * j) = (a ^ 0x80808080u) & m;
                     if (GEN && wn) {                          // the byte planes of a^2
@@ -921,8 +942,13 @@ hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
     if (!a.mx_flags || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
+    // The general form (nulls on the matrix cores) is taken where it beats the register-tiled kernel's sparse corrections: the small
+    // chips.  On the big ones it is bound by the LDS traffic of its extra operand planes at two to three workgroups per CU (measured at
+    // BASELINE C2, ocw 40: 86 ns per point against 66), so their null-ridden points go to that kernel; MIMC3_MX_GEN=0 / 1 forces either.
+    static const int gen_env = getenv("MIMC3_MX_GEN") ? atoi(getenv("MIMC3_MX_GEN")) : -1;
+    a.mx_gen_on = gen_env >= 0 ? gen_env : (a.ocw <= 16 ? 1 : 0);
     hipError_t e = launch_form<false>(a, stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !a.mx_gen_on) return e;
     a.point_flags = a.mx_flags; a.flag_value = kMxNulls;
     return launch_form<true>(a, stream);
 }
