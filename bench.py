@@ -31,16 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
-KERNEL_NAMES = {"u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dlc_px<PxF32i>",     # (PxF32i: the tiled f32 kernel on integral pixels; PxF32 otherwise) "u16_scaled": "match_ncc_dlc_px<PxU16>",
-                "u8_offset": "match_ncc_dlc_px<PxU8o>", "general_f32": "match_ncc_dlc_f32"}
-DTYPES = {"u8_exact": "u8", "u16_scaled": "u16", "u8_offset": "u8"}
+# (f32_tiled: PxF32i is the tiled f32 kernel on integral pixels; PxF32 otherwise)
+KERNEL_NAMES = {"u8_mfma": "match_ncc_dlc_mx", "u8_exact": "match_ncc_dlc_px<PxU8>", "f32_tiled": "match_ncc_dlc_px<PxF32i>",
+                "u16_scaled": "match_ncc_dlc_px<PxU16>", "u8_offset": "match_ncc_dlc_px<PxU8o>", "general_f32": "match_ncc_dlc_f32"}
+DTYPES = {"u8_mfma": "u8", "u8_exact": "u8", "u16_scaled": "u16", "u8_offset": "u8"}
 
 
 def kernel_source_sha16():
     """identifies the matcher kernel source the PMC figures in profiles/traffic_latest.json were measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("match_px_kernel.hip", "match_kernel.h", "sat_kernel.h"):
+    for f in ("match_mx_kernel.hip", "match_px_kernel.hip", "match_kernel.h", "sat_kernel.h"):
         with open(os.path.join(ROOT, "mimc3_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -269,8 +270,8 @@ def main():
                 rf["lds_peak_bytes_per_s"] = 75e12
             rf["pmc_kernel_sha16"] = tr.get("kernel_sha16")
             rf["pmc_stale"] = tr.get("kernel_sha16") != kernel_source_sha16()     # True: the kernel source changed after the PMC passes
-        except Exception:
-            pass
+        except Exception as e:      # (no PMC record for this kernel / config: say so instead of dropping the fields silently)
+            res["roofline"]["traffic_error"] = f"{type(e).__name__}: {e}"
         valid = got[:, 2] > -2.5
         res["check"] = {"valid_frac": float(valid.mean()),
                         "median_du_dv": [float(np.nanmedian(got[:, 0])), float(np.nanmedian(got[:, 1]))],

@@ -627,7 +627,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
         if (want_u8) {
             u.p0 = static_cast<const unsigned char *>(c->pl0.p); u.p1 = static_cast<const unsigned char *>(c->pl1.p);
             u.sat0 = c->sat0.p; u.sat1 = c->sat1.p; u.sat_ws = mimc3::sat_pitch(c->Wp);
-            if (tables_needed && c->path_mode == 0 && mimc3::match_mx_supported(ocw, max_npiv, c->win_half)) {
+            if (tables_needed && c->path_mode == 0 && mimc3::match_mx_supported(ocw, max_npiv, c->win_half, max_abs_piv_u, max_abs_piv_v)) {
                 // dense correlation surfaces on the matrix cores first; the points that kernel does not take (chips with nulls,
                 // corridors wider than its tile, ...) are redone by the register-tiled kernel in list mode, no host round trip
                 DevBuf &ml = c->mxl[c->lane];

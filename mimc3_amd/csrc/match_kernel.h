@@ -109,7 +109,7 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
 hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream);
 // dense correlation surfaces on the matrix cores (8-bit planes with tables; match_mx_kernel.hip): takes the points whose cell grid
 // fits its tile and whose chip has no null, leaves the others in a.mx_rest_list for launch_match_u8 in list mode
-bool match_mx_supported(int ocw, int max_npiv, int win_half);
+bool match_mx_supported(int ocw, int max_npiv, int win_half, int max_abs_u, int max_abs_v);
 hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream);
 
 // max_abs_u/v: max over points of |last pivot| per axis; max_npiv: max pivots per point.

@@ -913,12 +913,14 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
 
 }  // namespace mx
 
-bool match_mx_supported(int ocw, int max_npiv, int win_half)
+bool match_mx_supported(int ocw, int max_npiv, int win_half, int max_abs_u, int max_abs_v)
 {
     static const int off = getenv("MIMC3_MX") ? atoi(getenv("MIMC3_MX")) : 1;      // tuning / A-B: 0 = never take this kernel
     if (!off) return false;
     if (win_half > 0) return false;                   // full-square search areas (control-point stage): many pivots, not this kernel
-    (void)max_npiv;
+    // every point's pivots, with the ring of cells their first scans touch, must fit the 32 x 32 tile: a launch whose longest corridor
+    // does not (BASELINE C4: 31 pivots) is the register-tiled kernel's as a whole -- its points would only pass through here
+    if (max_npiv > 64 || max_abs_u > 29 || max_abs_v > 29) return false;
     return ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40;
 }
 

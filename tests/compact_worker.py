@@ -34,6 +34,7 @@ def main():
         off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
         with api.Context(0) as ctx:
             ctx.set_images(c.i0, c.i1)
+            ctx.set_path("u8px")           # the register-tiled kernel alone: its compact LDS form is what is tested
             res[name + "_fw"] = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
             assert ctx.last_path() == "u8_exact"
             res[name + "_sw"] = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)

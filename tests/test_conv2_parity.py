@@ -83,19 +83,19 @@ def test_filtered_passes_end_to_end(api, oracle, name):
     with api.Context(0) as ctx:
         ctx.set_images(c.i0, c.i1)
         raw = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == "u8_exact"
+        assert ctx.last_path() == "u8_mfma"
         ctx.filter_images(k)
         g0, g1 = ctx.get_images(H, W)
         assert_bits_equal(g0, f0, "filtered i0"); assert_bits_equal(g1, f1, "filtered i1")
         fw = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         # gradients of 8-bit data are integers (u8 kernel if they stay below 256, else the u8 kernel through per-point
         # offsets with the u16 kernel behind it), the Laplacian multiples of 1/8 (u16 kernel)
-        assert ctx.last_path() == ("u16_scaled" if name == "laplacian" else "u8_exact" if max(f0.max(), f1.max()) <= 255 else "u8_offset")
+        assert ctx.last_path() == ("u16_scaled" if name == "laplacian" else "u8_mfma" if max(f0.max(), f1.max()) <= 255 else "u8_offset")
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
         assert_bits_equal(fw, ref_fw, "forward"); assert_bits_equal(sw, ref_sw, "swapped")
         ctx.filter_images(None)                            # back to the raw pair
         assert_bits_equal(ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw), raw, "raw again")
-        assert ctx.last_path() == "u8_exact"
+        assert ctx.last_path() == "u8_mfma"
 
 
 def test_three_filters_reuse_the_output_planes(api, oracle):

@@ -62,7 +62,7 @@ def c2(api, checker):
     return c, off, uv, want
 
 
-@pytest.mark.parametrize("mode", ["auto", "u16", "f32", "general"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "u16", "f32", "general"])
 def test_c2_all_200k_points_vs_reference(api, c2, mode):
     c, off, uv, want = c2
     assert c.n == 200000
@@ -70,7 +70,7 @@ def test_c2_all_200k_points_vs_reference(api, c2, mode):
         ctx.set_images(c.i0, c.i1)
         ctx.set_path(mode)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == {"auto": "u8_exact", "u16": "u16_scaled", "f32": "f32_tiled", "general": "general_f32"}[mode]
+        assert ctx.last_path() == {"auto": "u8_mfma", "u8px": "u8_exact", "u16": "u16_scaled", "f32": "f32_tiled", "general": "general_f32"}[mode]
     assert_bits_equal(got, want, f"C2 {mode}")
     ok = got[:, 2] > 0.5
     assert ok.mean() > 0.9 and abs(np.median(got[ok, 0]) - 4) < 0.1 and abs(np.median(got[ok, 1]) + 4) < 0.1
@@ -152,7 +152,7 @@ def test_c4_shape_2048_all_points(api, checker):
     want = checker.match(i0, i1, xy, zero, off, uv, 32)
     with api.Context(0) as ctx:
         ctx.set_images(i0, i1)
-        for mode, path in (("auto", "u8_exact"), ("u16", "u16_scaled"), ("general", "general_f32")):
+        for mode, path in (("auto", "u8_exact"), ("u16", "u16_scaled"), ("general", "general_f32")):      # (31 pivots: wider than the matrix-core kernel's tile)
             ctx.set_path(mode)
             got = ctx.matching_ncc_dlc_2(xy, zero, off, uv, 32)
             assert ctx.last_path() == path

@@ -26,14 +26,14 @@ def expected_path(mode, i0, ocw, i1=None):
     is_u8 = all(float(i.max()) <= 255.0 and float(i.min()) >= 0 and np.array_equal(i, np.rint(i)) for i in imgs)
     is_si = all(float(i.min()) >= 0 and ((float(i.max()) <= 4095.0 and np.array_equal(i, np.rint(i))) or
                 (float(i.max()) * 8 <= 4095.0 and np.array_equal(i * 8, np.rint(i * 8)))) for i in imgs)
-    if mode == "auto" and ocw in U8_OCW and is_u8:
-        return "u8_exact"
-    if ocw in U8_OCW and ((mode == "auto" and is_si and not is_u8) or (mode == "u16" and is_u8)):
+    if mode in ("auto", "u8px") and ocw in U8_OCW and is_u8:
+        return "u8_mfma" if mode == "auto" else "u8_exact"     # the matrix-core kernel first ("auto"), or the register-tiled kernel alone
+    if ocw in U8_OCW and ((mode in ("auto", "u8px") and is_si and not is_u8) or (mode == "u16" and is_u8)):
         return "u16_scaled"
     return "f32_tiled" if (mode != "general" and ocw in F32T_OCW) else "general_f32"
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "general", "f32", "u16"])
 @pytest.mark.parametrize("path", golden_files("match_"), ids=lambda p: p.split("match_")[-1][:-4])
 def test_golden(api, path, mode):
     g = load_match_golden(path)
@@ -65,7 +65,7 @@ SMALL = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "general", "f32", "u16"])
 @pytest.mark.parametrize("kw", SMALL, ids=lambda k: f"seed{k['seed']}_ocw{k['ocw']}")
 def test_vs_oracle(api, oracle, kw, mode):
     c = synth.make_small(**kw)
@@ -82,7 +82,7 @@ def test_vs_oracle(api, oracle, kw, mode):
     assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "general", "f32", "u16"])
 def test_c1_config_vs_oracle(api, oracle, mode):
     """BASELINE configs[0]: 512^2, 1,024 points, 33x33 chip / 65x65 window."""
     c = synth.make_case("C1")
@@ -116,7 +116,7 @@ def test_float_images_within_tolerance(api, oracle):
     assert np.nanmax(np.abs(got - want)) <= 1e-4
 
 
-@pytest.mark.parametrize("mode", ["auto", "general", "f32", "u16"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "general", "f32", "u16"])
 def test_long_climbs(api, oracle, mode):
     """Smooth texture + a shift far along the corridor: pivots climb 10+ scans to the peak, which
     exercises the u8 kernel's generic (sequential) replay behind the speculative one."""
@@ -148,6 +148,7 @@ def test_u8_cache_overflow_hands_points_to_general_kernel(oracle):
         off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, c.ocw, H, W)
         with api.Context(0) as ctx:
             ctx.set_images(c.i0, c.i1)
+            ctx.set_path("u8px")           # the register-tiled kernel alone: its overflow hand-over is what is tested
             got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
             assert ctx.last_path() == "u8_exact"
         np.save(sys.argv[1], got)
@@ -202,11 +203,13 @@ def test_all_four_cli_chip_sizes_on_one_pair(api, oracle):
         ctx.set_images(c.i0, c.i1)
         for ocw in (7, 15, 30, 40):
             off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
-            fwd = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
-            assert ctx.last_path() == "u8_exact"
-            assert_bits_equal(fwd, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, ocw), f"ocw{ocw} fwd")
-            sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
-            assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), f"ocw{ocw} swapped")
+            for mode, path in (("auto", "u8_mfma"), ("u8px", "u8_exact")):
+                ctx.set_path(mode)
+                fwd = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
+                assert ctx.last_path() == path
+                assert_bits_equal(fwd, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, ocw), f"ocw{ocw} fwd {mode}")
+                sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
+                assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), f"ocw{ocw} swapped {mode}")
 
 
 @pytest.mark.parametrize("null_frac", [0.10, 0.30])
@@ -221,7 +224,7 @@ def test_big_chips_with_many_nulls(api, oracle, ocw, null_frac):
     off, uv = api.get_uv_pivot(c.xyuvav, c.dt, c.mpp, ocw, H, W)
     with api.Context(0) as ctx:
         ctx.set_images(c.i0, c.i1)
-        for mode, path in (("auto", "u8_exact"), ("u16", "u16_scaled")):
+        for mode, path in (("auto", "u8_mfma"), ("u8px", "u8_exact"), ("u16", "u16_scaled")):
             ctx.set_path(mode)
             got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
             assert ctx.last_path() == path
@@ -232,7 +235,7 @@ def test_big_chips_with_many_nulls(api, oracle, ocw, null_frac):
         ctx.filter_images(api.CLI_KERNELS[0])
         f0, f1 = ctx.get_images(H, W)
         gf = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
-        assert ctx.last_path() in ("u8_exact", "u8_offset", "u16_scaled")
+        assert ctx.last_path() in ("u8_mfma", "u8_exact", "u8_offset", "u16_scaled")
         assert_bits_equal(gf, oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, ocw), "d/dx")
 
 
@@ -256,7 +259,7 @@ def test_offsets_from_tile_ranges_or_from_the_full_scan(api, oracle, ocw, monkey
         monkeypatch.setenv("MIMC3_NO_RANGE_TILES", "1")
         b = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, ocw)
         monkeypatch.delenv("MIMC3_NO_RANGE_TILES")
-    assert path in ("u8_offset", "u16_scaled", "u8_exact")
+    assert path in ("u8_offset", "u16_scaled", "u8_exact", "u8_mfma")
     assert_bits_equal(a, want, "tile bound")
     assert_bits_equal(b, want, "full scan")
 
@@ -360,7 +363,7 @@ def test_16bit_and_float_imagery_on_the_tiled_f32_kernel(api, oracle, ocw, kind)
         assert_bits_equal(got, want, "tiled, 16-bit"); assert_bits_equal(gen, want, "general, 16-bit")
 
 
-@pytest.mark.parametrize("mode", ["auto", "u16", "f32", "general"])
+@pytest.mark.parametrize("mode", ["auto", "u8px", "u16", "f32", "general"])
 @pytest.mark.parametrize("reach", [60, 100])
 def test_long_corridor_big_chip_falls_back_when_lds_is_short(api, oracle, reach, mode):
     """A fast a-priori on the largest CLI chip (ocw 40): the window (2*(reach+42)+1)^2 outgrows the 160 KB LDS carve of
@@ -382,7 +385,7 @@ def test_long_corridor_big_chip_falls_back_when_lds_is_short(api, oracle, reach,
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         path = ctx.last_path()
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
-    expect = {(60, "auto"): "u8_exact", (60, "u16"): "general_f32", (60, "f32"): "general_f32", (60, "general"): "general_f32",
+    expect = {(60, "auto"): "u8_exact", (60, "u8px"): "u8_exact", (100, "u8px"): "general_f32", (60, "u16"): "general_f32", (60, "f32"): "general_f32", (60, "general"): "general_f32",
               (100, "auto"): "general_f32", (100, "u16"): "general_f32", (100, "f32"): "general_f32", (100, "general"): "general_f32"}
     assert path == expect[(reach, mode)]
     assert_bits_equal(got, want)
@@ -407,7 +410,7 @@ def test_corridor_of_more_than_64_pivots(api, oracle, ocw, angle, mode):
         ctx.set_images(c.i0, c.i1)
         ctx.set_path(mode)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == {"auto": "u8_exact", "u16": "u16_scaled"}[mode]
+        assert ctx.last_path() == {"auto": "u8_exact", "u16": "u16_scaled"}[mode]      # (the many-pivot forms of the register-tiled kernels: no tables, no matrix-core pass)
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
         assert_bits_equal(got, oracle.match(c.i0, c.i1, c.xyuvav, c.offset, off, uv, c.ocw))
         assert_bits_equal(sw, oracle.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, c.ocw), "swapped")
@@ -415,7 +418,7 @@ def test_corridor_of_more_than_64_pivots(api, oracle, ocw, angle, mode):
             ctx.filter_images(api.CLI_KERNELS[0])
             f0, f1 = ctx.get_images(H, W)
             gf = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-            assert ctx.last_path() in ("u8_exact", "u8_offset", "u16_scaled")      # (small gradients can still be 8-bit)
+            assert ctx.last_path() in ("u8_mfma", "u8_exact", "u8_offset", "u16_scaled")      # (small gradients can still be 8-bit)
             assert_bits_equal(gf, oracle.match(f0, f1, c.xyuvav, c.offset, off, uv, c.ocw), "d/dx")
 
 

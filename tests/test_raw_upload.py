@@ -35,7 +35,7 @@ def test_raw_dn_equals_host_widening(api, oracle, bits, w, pinned):
         g0, g1 = ctx.get_images(H, W)
         assert np.array_equal(g0, c.i0) and np.array_equal(g1, c.i1)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == ("u8_exact" if bits == 8 else "f32_tiled")
+        assert ctx.last_path() == ("u8_mfma" if bits == 8 else "f32_tiled")
         assert_bits_equal(got, want, "raw upload")
         # filtered passes start from the widened f32 pair
         ctx.filter_images(api.CLI_KERNELS[0])
