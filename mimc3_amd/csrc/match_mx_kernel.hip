@@ -449,23 +449,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         };
         const unsigned char *zrow = smem + C::OFF_Z + (arow - WT);         // the null plane under the lane's A operand (ZPL)
         (void)zrow;
-        struct RowOps { v4i a[2][KCW]; v4i az[C::ZPL ? 2 : 1][KCW]; uint32_t d[C::NPL][KCW][5]; };
+        // (double-buffered across rows: the tile rows and the a' plane.  The general form's other operands -- the a^2 planes, the null plane --
+        //  are read at the start of a row's turn and used at its end, behind the MFMAs that do not need them: half the operand registers)
+        struct RowOps { v4i a[2][KCW]; uint32_t d[KCW][5]; };
         auto issue = [&](int r, RowOps &o) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int c = 0; c < KCW; c++) {
-                    o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
-                    if constexpr (C::ZPL) o.az[m][c] = *reinterpret_cast<const v4i *>(zrow + (r + 16 * m) * PW + 64 * c);
-                }
+                for (int c = 0; c < KCW; c++) o.a[m][c] = *reinterpret_cast<const v4i *>(arow + (r + 16 * m) * PW + 64 * c);
 #pragma unroll
-            for (int pl = 0; pl < C::NPL; pl++)
+            for (int c = 0; c < KCW; c++) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + CP * r + 64 * c);
 #pragma unroll
-                for (int c = 0; c < KCW; c++) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(brow + pl * C::CHB + CP * r + 64 * c);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) o.d[pl][c][k] = q[k];
-                }
+                for (int k = 0; k < 5; k++) o.d[c][k] = q[k];
+            }
         };
         auto shifted = [&](const uint32_t (&d)[KCW][5], v4i (&b)[KCW]) __attribute__((always_inline)) {
 #pragma unroll
@@ -475,8 +472,24 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         };
         // (the null-plane operands are 0x80 = -128 per null: their correlations come out times -128, their product times 16384)
         auto consume = [&](const RowOps &o, int r) __attribute__((always_inline)) {
+            [[maybe_unused]] uint32_t d1[KCW][5], d2[KCW][5];
+            [[maybe_unused]] v4i az[2][KCW];
+            if constexpr (GEN) {
+#pragma unroll
+                for (int c = 0; c < KCW; c++) {
+                    const uint32_t *q1 = reinterpret_cast<const uint32_t *>(brow + C::CHB + CP * r + 64 * c), *q2 = reinterpret_cast<const uint32_t *>(brow + 2 * C::CHB + CP * r + 64 * c);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { d1[c][k] = q1[k]; d2[c][k] = q2[k]; }
+                }
+                if constexpr (C::ZPL) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int c = 0; c < KCW; c++) az[m][c] = *reinterpret_cast<const v4i *>(zrow + (r + 16 * m) * PW + 64 * c);
+                }
+            }
             v4i b[KCW];
-            shifted(o.d[0], b);
+            shifted(o.d, b);
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -485,14 +498,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                 const bool cnrow = cn && row_has_null(r);
                 v4i z[2][KCW];
                 if (wn) {
-                    v4i blo[KCW], bhi[KCW];
-                    shifted(o.d[1], blo); shifted(o.d[2], bhi);
 #pragma unroll
                     for (int m = 0; m < 2; m++)
 #pragma unroll
                         for (int c = 0; c < KCW; c++) {
-                            if constexpr (C::ZPL) z[m][c] = o.az[m][c]; else z[m][c] = null80v(o.a[m][c]);
-                            accz[m] = mfma(z[m][c], b[c], accz[m]); accl[m] = mfma(z[m][c], blo[c], accl[m]); acch[m] = mfma(z[m][c], bhi[c], acch[m]);
+                            if constexpr (C::ZPL) z[m][c] = az[m][c]; else z[m][c] = null80v(o.a[m][c]);
+                            accz[m] = mfma(z[m][c], b[c], accz[m]);
                         }
                 }
                 if (cnrow) {
@@ -507,6 +518,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                             if (wn) acczz[m] = mfma(z[m][c], za, acczz[m]);
                         }
                     }
+                }
+                if (wn) {
+                    v4i bq[KCW];
+                    shifted(d1, bq);
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int c = 0; c < KCW; c++) accl[m] = mfma(z[m][c], bq[c], accl[m]);
+                    shifted(d2, bq);
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+#pragma unroll
+                        for (int c = 0; c < KCW; c++) acch[m] = mfma(z[m][c], bq[c], acch[m]);
                 }
             }
         };
@@ -523,6 +547,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             consume(o1, r + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (GEN) {        // the two byte planes of each squared operand back into one sum (and out of the -128 scale): 16 registers fewer from here on
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                accl[m][i] = ((-accl[m][i]) >> 7) + 256 * ((-acch[m][i]) >> 7);
+                accyl[m][i] = ((-accyl[m][i]) >> 7) + 256 * ((-accyh[m][i]) >> 7);
+            }
     }
     MIMC3_MX_STAMP(1)
 
@@ -657,11 +690,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             sxy = acc[m][i] + 128 * ((int)SXo + sy) - 16384 * NPX;          // (over all chip positions: a null is a zero factor)
             if (GEN && cn) {                                   // chip nulls take window pixels out of sy, syy
                 sy -= ((-accy[m][i]) >> 7) + 128 * Na;
-                syy -= (((-accyl[m][i]) >> 7) + 128 * Na) + 256 * (((-accyh[m][i]) >> 7) + 128 * Na);
+                syy -= accyl[m][i] + (128 + 256 * 128) * Na;
             }
             if (GEN && wn) {                                   // window nulls (T4 among them) take chip pixels out of n, sx, sxx
                 const int nz = boxz[m][i];
-                const int ca = ((-accz[m][i]) >> 7) + 128 * nz, caa = (((-accl[m][i]) >> 7) + 128 * nz) + 256 * (((-acch[m][i]) >> 7) + 128 * nz);
+                const int ca = ((-accz[m][i]) >> 7) + 128 * nz, caa = accl[m][i] + (128 + 256 * 128) * nz;
                 dn = (double)(NPX - Na - nz + (cn ? (acczz[m][i] >> 14) : 0)); dsx = (double)((int)SXo - ca);
                 va = dn * (double)((int)SXXo - caa) - dsx * dsx;
             } else {
@@ -686,6 +719,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             const uint32_t low = ((uint32_t)__double2loint(q) & 0x1fffffffu) - (0x10000000u - 0x2000u);     // distance to the f32 rounding boundary, + 2^13
             if (!(P > 0.0) || low <= 0x4000u) amb |= 1u << ci;
             val[ry * VP + sx_col] = (float)q;
+            if constexpr (GEN) __builtin_amdgcn_sched_barrier(0);      // (general form: one cell at a time -- interleaved, the cells' f64 temporaries spill)
         }
         if (__any(amb != 0u)) {                            // rare (2^-15 of the cells): the reference's own operations
 #pragma unroll
@@ -944,11 +978,12 @@ hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
     if (!a.mx_flags || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
-    // The general form (nulls on the matrix cores) is taken where it beats the register-tiled kernel's sparse corrections: the small
-    // chips.  On the big ones it is bound by the LDS traffic of its extra operand planes at two to three workgroups per CU (measured at
-    // BASELINE C2, ocw 40: 86 ns per point against 66), so their null-ridden points go to that kernel; MIMC3_MX_GEN=0 / 1 forces either.
-    static const int gen_env = getenv("MIMC3_MX_GEN") ? atoi(getenv("MIMC3_MX_GEN")) : -1;
-    a.mx_gen_on = gen_env >= 0 ? gen_env : (a.ocw <= 16 ? 1 : 0);
+    // The general form (nulls on the matrix cores) is built, tested and bit-identical at every chip size, but it is not the default: at
+    // BASELINE C2 it costs 19 ns per null-ridden point at ocw 16 (the register-tiled kernel's sparse corrections: 18) and 86 ns at
+    // ocw 40 (66) -- its extra operand planes leave two to three workgroups per CU.  So the clean form takes the points without nulls
+    // (9 ns against 15 at ocw 16, 40 against 66 at ocw 40) and hands the others to that kernel; MIMC3_MX_GEN=1 turns the general form on.
+    static const int gen_env = getenv("MIMC3_MX_GEN") ? atoi(getenv("MIMC3_MX_GEN")) : 0;
+    a.mx_gen_on = gen_env != 0 ? 1 : 0;
     hipError_t e = launch_form<false>(a, stream);
     if (e != hipSuccess || !a.mx_gen_on) return e;
     a.point_flags = a.mx_flags; a.flag_value = kMxNulls;

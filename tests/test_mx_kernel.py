@@ -47,10 +47,11 @@ def test_every_chip_size_clean_and_with_nulls(api, oracle, ocw, null_frac):
         both_directions(api, ctx, c, off, uv, ocw, oracle, f"ocw {ocw} nulls {null_frac}")
 
 
-@pytest.mark.parametrize("ocw", (16, 40))
-def test_general_form_on_big_chips_too(ocw):
-    """The general form is not the default on the big chips (the register-tiled kernel takes their null-ridden points): forced on,
-    it must still give the oracle's bits (a subprocess: the switch is read once per process)."""
+@pytest.mark.parametrize("ocw", MX_OCW)
+def test_general_form(ocw):
+    """The general form (window and chip nulls on the matrix cores) is not the default -- the register-tiled kernel takes the
+    null-ridden points: switched on, it must give the oracle's bits at every chip size (a subprocess: the switch is read once per
+    process)."""
     code = textwrap.dedent("""
         import sys, numpy as np
         sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
