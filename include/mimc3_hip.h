@@ -321,6 +321,11 @@ int mimc3_partition_points(const double *cost, int32_t N, int32_t world, int32_t
                            int32_t *start /*[world+1]*/, double *imbalance /*may be NULL*/);
 typedef struct mimc3_mgpu mimc3_mgpu;
 int  mimc3_mgpu_create(const int32_t *devices, int32_t ndev, mimc3_mgpu **out);   /* a context per device + the communicator */
+/* Test / bring-up form of the above (the product entry point never takes these, and the library reads neither from the environment):
+ * comm_lib = a library exporting the six RCCL entry points the driver uses (NULL: RCCL); MIMC3_MGPU_REPEAT_DEVICES in flags lets a
+ * device be listed more than once (N ranks as N contexts of one GPU over a stand-in communicator). */
+#define MIMC3_MGPU_REPEAT_DEVICES 1u
+int  mimc3_mgpu_create_ex(const int32_t *devices, int32_t ndev, const char *comm_lib, uint32_t flags, mimc3_mgpu **out);
 void mimc3_mgpu_destroy(mimc3_mgpu *mg);
 int32_t mimc3_mgpu_ndev(mimc3_mgpu *mg);
 mimc3_ctx *mimc3_mgpu_ctx(mimc3_mgpu *mg, int32_t rank);

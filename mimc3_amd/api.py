@@ -129,6 +129,7 @@ _lib.mimc3_ctx_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
 _lib.mimc3_point_cost.argtypes = [_i64p, C.c_int32, C.c_int32, _f64p]
 _lib.mimc3_partition_points.argtypes = [_f64p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, C.POINTER(C.c_double)]
 _lib.mimc3_mgpu_create.argtypes = [_i32p, C.c_int32, C.POINTER(_vp)]
+_lib.mimc3_mgpu_create_ex.argtypes = [_i32p, C.c_int32, C.c_char_p, C.c_uint32, C.POINTER(_vp)]
 _lib.mimc3_mgpu_destroy.argtypes = [_vp]
 _lib.mimc3_mgpu_destroy.restype = None
 _lib.mimc3_mgpu_ndev.argtypes = [_vp]
@@ -263,10 +264,14 @@ def partition_points(cost, world, block=1024):
 class MultiGpu:
     """mimc3_mgpu: ONE process driving several GPUs (a host thread per device, RCCL communicator over them)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, comm_lib=None, repeat_devices=False):
+        """comm_lib / repeat_devices: the test form (mimc3_mgpu_create_ex) -- a stand-in communicator library, N ranks on one device."""
         self._h = _vp()
         dv = np.ascontiguousarray(devices, np.int32)
-        _check(_lib.mimc3_mgpu_create(dv, dv.shape[0], C.byref(self._h)), "mgpu_create")
+        if comm_lib or repeat_devices:
+            _check(_lib.mimc3_mgpu_create_ex(dv, dv.shape[0], comm_lib.encode() if comm_lib else None, 1 if repeat_devices else 0, C.byref(self._h)), "mgpu_create_ex")
+        else:
+            _check(_lib.mimc3_mgpu_create(dv, dv.shape[0], C.byref(self._h)), "mgpu_create")
         self.ndev = dv.shape[0]
 
     def close(self):

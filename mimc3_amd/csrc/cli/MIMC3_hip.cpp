@@ -181,6 +181,12 @@ int main(int argc, char *argv[])
     int ctx_rc = 0;
     std::string ctx_err;
     std::thread ctx_thread([&]() {
+#ifdef MIMC3_TEST_HOOKS      // test build only (tests/_build/MIMC3_hip_test): N ranks on one device over a stand-in communicator
+        if (!devs.empty() && (getenv("MIMC3_TEST_COMM_LIB") || getenv("MIMC3_TEST_REPEAT"))) {
+            const char *rp = getenv("MIMC3_TEST_REPEAT");
+            ctx_rc = mimc3_mgpu_create_ex(devs.data(), (int32_t)devs.size(), getenv("MIMC3_TEST_COMM_LIB"), (rp && rp[0] == '1') ? MIMC3_MGPU_REPEAT_DEVICES : 0u, &mg);
+        } else
+#endif
         ctx_rc = devs.empty() ? mimc3_ctx_create(dev ? atoi(dev) : 0, &ctx) : mimc3_mgpu_create(devs.data(), (int32_t)devs.size(), &mg);
         if (ctx_rc) ctx_err = mimc3_last_error();
     });

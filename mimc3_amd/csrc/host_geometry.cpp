@@ -7,7 +7,10 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/mimc3_hip.h"
@@ -69,19 +72,72 @@ struct Corridor {
 }  // namespace
 
 namespace {
-// points are independent: the passes run on a few host threads
+// Points are independent: the passes run on a few host threads -- a persistent pool, started on first use.  (Threads started per
+// call cost ~1.8 ms of a 200,000-point corridor pass, as much as its atan2 / cos / sin: VERDICT round 3, item 7.)  The workers are
+// detached and never joined: a process may leave through _exit (the command line does), and static destructors must not wait on them.
+class Pool {
+public:
+    static Pool &get() { static Pool *p = new Pool(); return *p; }
+    // runs body(b, e) over [0, N) in chunks; returns when all are done.  One job at a time: a second caller (another host thread of a
+    // multi-GPU driver) finds the pool busy and runs its loop itself.
+    template <class Body> void run(int32_t N, int32_t chunk, Body &&body)
+    {
+        std::unique_lock<std::mutex> busy(job_mu_, std::try_to_lock);
+        if (!busy.owns_lock() || workers_ == 0) { body(0, N); return; }
+        std::function<void(int32_t, int32_t)> fn = body;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = N; chunk_ = chunk; next_.store(0); pending_ = workers_; gen_++;
+        }
+        cv_job_.notify_all();
+        work();                                              // the caller takes chunks too
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    Pool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        workers_ = (int)(hw > 64 ? 64 : hw) - 1;
+        if (workers_ < 0) workers_ = 0;
+        for (int i = 0; i < workers_; i++) std::thread([this] { loop(); }).detach();
+    }
+    void work()
+    {
+        for (;;) {
+            const int32_t b = next_.fetch_add(chunk_);
+            if (b >= n_) break;
+            (*fn_)(b, b + chunk_ < n_ ? b + chunk_ : n_);
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_job_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_job_, cv_done_;
+    const std::function<void(int32_t, int32_t)> *fn_ = nullptr;
+    int32_t n_ = 0, chunk_ = 1;
+    std::atomic<int32_t> next_{0};
+    int workers_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+};
+
 template <class Body> void run_threads(int32_t N, Body &&body)
 {
-    // (at least ~4,000 points per thread: below that the thread start costs more than the loop)
-    unsigned nt = N >= 20000 ? std::thread::hardware_concurrency() : 1;
-    const unsigned by_work = (unsigned)(N / 4000) + 1;
-    nt = nt > 64 ? 64 : (nt < 1 ? 1 : nt);
-    nt = nt > by_work ? by_work : nt;
-    if (nt == 1) { body(0, N); return; }
-    std::vector<std::thread> th;
-    const int32_t step = (N + (int32_t)nt - 1) / (int32_t)nt;
-    for (int32_t b = 0; b < N; b += step) th.emplace_back(body, b, b + step < N ? b + step : N);
-    for (auto &t : th) t.join();
+    if (N < 8000) { body(0, N); return; }                    // (below that the hand-over costs more than the loop)
+    Pool::get().run(N, 2048, body);
 }
 }  // namespace
 

@@ -40,12 +40,14 @@ struct Rccl {
 };
 constexpr int kNcclFloat = 7;          // ncclFloat32 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5, ncclFloat16 6, ncclFloat32 7)
 
-Rccl &rccl()
+// The communicator library is loaded once per process, on first use; `lib` (mimc3_mgpu_create_ex: tests hand in a stand-in with the same
+// six entry points) only matters on that first call.  Nothing here reads the environment.
+Rccl &rccl(const char *lib = nullptr)
 {
     static Rccl r;
     static std::once_flag once;
-    std::call_once(once, []() {
-        const char *names[] = {getenv("MIMC3_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    std::call_once(once, [lib]() {
+        const char *names[] = {lib, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char *n : names) {
             if (!n || !*n) continue;
             r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -141,17 +143,22 @@ extern "C" int mimc3_partition_points(const double *cost, int32_t N, int32_t wor
 // ---- lifetime -----------------------------------------------------------------------------------------------------------
 extern "C" int mimc3_mgpu_create(const int32_t *devices, int32_t ndev, mimc3_mgpu **out)
 {
+    return mimc3_mgpu_create_ex(devices, ndev, nullptr, 0u, out);
+}
+
+// The form the tests use: `comm_lib` names a library that exports the six RCCL entry points used here (null = RCCL itself);
+// flags & MIMC3_MGPU_REPEAT_DEVICES lets a device be listed several times, so that a one-GPU box can run N ranks as N contexts of the
+// same device over a stand-in communicator (tests/fake_rccl.c -- RCCL refuses such a list).  It measures nothing and is not a product
+// mode; the product entry point above never takes either, and nothing in this library reads them from the environment.
+extern "C" int mimc3_mgpu_create_ex(const int32_t *devices, int32_t ndev, const char *comm_lib, uint32_t flags, mimc3_mgpu **out)
+{
     if (!out || !devices || ndev <= 0 || ndev > 64) return mimc3::fail(MIMC3_EINVAL, "mimc3_mgpu_create: bad argument");
     *out = nullptr;
-    // One rank per GPU.  TEST-ONLY switch: MIMC3_MGPU_ALLOW_REPEAT=1 lets a device be listed several times, so that a
-    // one-GPU box can run N ranks as N contexts of the same device (together with a stand-in communicator selected through
-    // MIMC3_RCCL_LIB, tests/fake_rccl.c -- RCCL itself refuses such a device list); it measures nothing and is not a product mode.
-    const char *rep = getenv("MIMC3_MGPU_ALLOW_REPEAT");
-    if (!(rep && rep[0] == '1'))
+    if (!(flags & MIMC3_MGPU_REPEAT_DEVICES))           // one rank per GPU
         for (int32_t a = 0; a < ndev; a++)
             for (int32_t b = a + 1; b < ndev; b++)
                 if (devices[a] == devices[b]) return mimc3::fail(MIMC3_EINVAL, "mimc3_mgpu_create: a device is listed twice (one rank per GPU)");
-    Rccl &r = rccl();
+    Rccl &r = rccl(comm_lib && *comm_lib ? comm_lib : nullptr);
     if (!r.err.empty()) return mimc3::fail(MIMC3_ENODEV, "mimc3_mgpu_create: " + r.err);
     mimc3_mgpu *mg = new mimc3_mgpu();
     mg->dev.assign(devices, devices + ndev);

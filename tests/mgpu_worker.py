@@ -36,7 +36,7 @@ def c3_case(out_path, devices):
         ctx.set_images(c.i0, c.i1)
         res["match_one"] = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         one = ctx.vmap(xv, 16.0, cp_seed=7)
-    with api.MultiGpu(devices) as mg:
+    with api.MultiGpu(devices, comm_lib=os.environ.get("MIMC3_TEST_COMM_LIB") or None, repeat_devices=os.environ.get("MIMC3_TEST_REPEAT") == "1") as mg:
         mg.set_images(i0r, i1r)
         res["match_mg"] = mg.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         res["imbalance_match"] = np.float64(mg.last_imbalance())
@@ -51,7 +51,7 @@ def c3_case(out_path, devices):
 
 def fake_collectives():
     """completed all-gathers of the stand-in communicator (tests/fake_rccl.c), -1 when the real RCCL is in use"""
-    lib = os.environ.get("MIMC3_RCCL_LIB", "")
+    lib = os.environ.get("MIMC3_TEST_COMM_LIB", "")
     if "fake_rccl" not in lib:
         return -1
     import ctypes
@@ -81,7 +81,7 @@ def main():
     with api.Context(devices[0]) as ctx:
         ctx.set_images(i0, i1)
         one = ctx.vmap(vxy, 16.0, cp_seed=7, num_cp_min=20)
-    with api.MultiGpu(devices) as mg:
+    with api.MultiGpu(devices, comm_lib=os.environ.get("MIMC3_TEST_COMM_LIB") or None, repeat_devices=os.environ.get("MIMC3_TEST_REPEAT") == "1") as mg:
         mg.set_images(c.i0.astype(np.uint8), c.i1.astype(np.uint8))          # raw 8-bit DN, replicated
         res["match_mg"] = mg.matching_ncc_dlc_2(xy, c.offset, off, uv, c.ocw)
         res["imbalance_match"] = np.float64(mg.last_imbalance())

@@ -5,9 +5,10 @@ the device or on the rank that matched it).
 Two ways of running it:
   * real RCCL over the devices in MIMC3_TEST_DEVICES (default "0": a one-rank communicator on the one-GPU test box;
     "0,1,..." on a multi-GPU node) -- the transport test;
-  * N ranks on ONE device (ids "0,0", "0,0,0,0", eight times 0): MIMC3_MGPU_ALLOW_REPEAT=1 lets the driver take a repeated
-    device, and tests/fake_rccl.c stands in for the communicator (device-to-device copies ordered by events) through the
-    driver's MIMC3_RCCL_LIB hook.  One process, N host threads, N contexts: every N > 1 branch of mgpu.cpp runs (per-rank
+  * N ranks on ONE device (ids "0,0", "0,0,0,0", eight times 0): the test form of the create call (mimc3_mgpu_create_ex) lets
+    the driver take a repeated device and a stand-in communicator, tests/fake_rccl.c (device-to-device copies ordered by
+    events).  The library reads neither from the environment; the variables below are read by the TEST programs (the worker, and a
+    test build of the command line, -DMIMC3_TEST_HOOKS) and passed as arguments.  One process, N host threads, N contexts: every N > 1 branch of mgpu.cpp runs (per-rank
     threads, cost-balanced shares incl. ranks that get no block, padded blocks, the grouped all-gather, the un-permute over
     several ranks' blocks, post-processing on rank 0) -- what it cannot show is xGMI transport or scaling."""
 import os
@@ -24,6 +25,14 @@ pytestmark = pytest.mark.gpu
 
 DEVICES = os.environ.get("MIMC3_TEST_DEVICES", "0")
 CLI = os.path.join(ROOT, "mimc3_amd", "csrc", "MIMC3_hip")
+CLI_TEST = os.path.join(ROOT, "tests", "_build", "MIMC3_hip_test")      # the command line built with -DMIMC3_TEST_HOOKS (takes the stand-in communicator)
+
+
+def cli_test_build():
+    src = os.path.join(ROOT, "mimc3_amd", "csrc", "cli", "MIMC3_hip.cpp")
+    if not os.path.exists(CLI_TEST) or os.path.getmtime(CLI_TEST) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mimc3_amd", "csrc"), "cli_test"])
+    return CLI_TEST
 FAKE_SRC = os.path.join(ROOT, "tests", "fake_rccl.c")
 FAKE_LIB = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
 
@@ -40,8 +49,8 @@ def worker_env(ranks_on_one_device):
     env = dict(os.environ)
     env.pop("LD_PRELOAD", None)
     if ranks_on_one_device:
-        env["MIMC3_RCCL_LIB"] = fake_rccl()
-        env["MIMC3_MGPU_ALLOW_REPEAT"] = "1"
+        env["MIMC3_TEST_COMM_LIB"] = fake_rccl()
+        env["MIMC3_TEST_REPEAT"] = "1"
     return env
 
 
@@ -116,7 +125,7 @@ def test_cli_with_device_list(tmp_path):
         os.makedirs(f"{d}/out")
         fileio.write_tiff(f"{d}/{t0}_i0.tif", z["i0"].astype(np.uint8)); fileio.write_tiff(f"{d}/{t1}_i1.tif", z["i1"].astype(np.uint8))
         fileio.write_gma(f"{d}/xyuvav.GMA", z["xyuvav"])
-        p = subprocess.run([CLI, f"{d}/{t0}_i0.tif", f"{d}/{t1}_i1.tif", f"{d}/xyuvav.GMA", f"{d}/out"],
+        p = subprocess.run([cli_test_build() if fake else CLI, f"{d}/{t0}_i0.tif", f"{d}/{t1}_i1.tif", f"{d}/xyuvav.GMA", f"{d}/out"],
                            env=dict(worker_env(fake), MIMC3_CP_SEED=str(int(z["seed"])), MIMC3_HIP_DEVICES=devices), capture_output=True, text=True)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         assert "sharded over" in p.stdout
