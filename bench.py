@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4"])
-    ap.add_argument("--path", default="auto", choices=["auto", "general", "f32", "u16"],
+    ap.add_argument("--path", default="auto", choices=["auto", "u8px", "general", "f32", "u16"],
                     help="auto: exact u8 kernel when the pair is 8-bit integral; f32: the register-tiled f32 kernel "
                          "(what 16-bit / filtered imagery gets); general: force the fallback f32 kernel")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-program", action="store_true",
                     help="skip the extra `program` object (the reference program's whole data path, mimc3_vmap, once)")
     ap.add_argument("--no-f32-path", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (register-tiled kernel alone, null-free pair, the program's 32 passes)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid points for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
@@ -260,9 +261,15 @@ def main():
             rf["traffic_source"] = tr["source"] + " (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; measured in separate --pmc passes, not in this run)"
             # SURVEY 8(d)'s secondary bounds: the kernel is VALU-issue-bound, not HBM-bound (traffic << algorithmic bytes)
             for k in ("valu_per_point", "salu_per_point", "lds_per_point", "valu_busy", "waves_per_simd", "wait_share_of_wave_time",
-                      "issue_stall_share_of_wave_time", "issuing_share_of_wave_time"):
+                      "issue_stall_share_of_wave_time", "issuing_share_of_wave_time", "kernel_ms_profile_avg", "kernels"):
                 if k in tr:
                     rf[k] = tr[k]
+            # what bounds the pass, by the counters: its HBM traffic is a few percent of the algorithmic bytes, its time goes into issuing
+            # (VALU + MFMA + SALU) and into the latency of short dependent chains
+            if "bound" in tr:
+                rf["bound"] = tr["bound"]
+            if "compute" in tr:
+                rf["compute"] = tr["compute"]
             if "lds_per_point" in tr and kern_ms > 0:
                 # LDS wave-instructions x 64 lanes x 4 B (the kernel's LDS traffic is ds_read_b32 / ds_read2_b32) over the live kernel time;
                 # the ds_read_b32 peak of the chip is ~75 TB/s (MI355X_MICROARCH.md, LDS)
@@ -285,10 +292,15 @@ def main():
             if not args.no_f32_path and args.path == "auto" and path != "f32_tiled":
                 res["f32_path"] = f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, cpu)
                 ctx.set_path(args.path)
+            if not args.no_legs and args.path == "auto" and path == "u8_mfma":
+                res["kernels"] = kernel_legs(torch, dist, dev, api, synth, ctx, leg, make_step, piv_off, piv_uv, case, args, got)
+                ctx.set_path(args.path)
         if args.qm_sweeps > 0:
             res["qm"] = qm_leg(torch, api, synth, ctx, dev, case, args.qm_sweeps, check=(world == 1 and not args.no_cpu_baseline))
         if world == 1 and not args.no_program:
             res["program"] = program_leg(api, ctx, xy_all)
+            if not args.no_legs:
+                res["program"]["passes"] = passes_leg(torch, api, ctx, dev, case, xy_all)
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
@@ -344,7 +356,7 @@ def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, 
     ach = alg / (kern_ms * 1e-3) / 1e9
     out = {"kernel_path": ctx.last_path(), "value": leg.n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "kernel": KERNEL_NAMES["f32_tiled"], "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg}}
+                        "kernel": KERNEL_NAMES.get(ctx.last_path(), ctx.last_path()), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg}}
     if cpu is not None:
         idx, ref = cpu
         g = leg.d_out.cpu().numpy()[idx]
@@ -352,6 +364,73 @@ def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, 
         out["parity"] = {"points": int(len(idx)), "invalid_mask_equal": nan_same,
                          "max_abs_diff_px": float(np.nanmax(np.abs(g - ref))) if np.isfinite(ref).any() else 0.0,
                          "bit_identical": bool(nan_same and np.array_equal(np.nan_to_num(g).view(np.uint32), np.nan_to_num(ref).view(np.uint32)))}
+    return out
+
+
+def kernel_legs(torch, dist, dev, api, synth, ctx, leg, make_step, piv_off, piv_uv, case, args, got):
+    """Secondary figures beside `value` (same workload, same timer): the register-tiled kernel alone (mode "u8px": what round 3 measured),
+    and the same grid on a NULL-FREE pair -- every point then takes the matrix-core kernel's clean form, which is the rate of imagery
+    without void areas (the config's pair has 2 % of each image zeroed in blobs: 52 % of its points hold a null in chip or window and
+    are the register-tiled kernel's)."""
+    out = {}
+    ctx.set_path("u8px")
+    leg.d_out.fill_(float("nan"))
+    el, km = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+    g = leg.d_out.cpu().numpy()
+    out["register_tiled_alone"] = {"kernel_path": ctx.last_path(), "ms_per_step": el / args.steps * 1e3, "kernel_ms": km, "value": leg.n * args.steps / el,
+                                   "bit_identical_to_headline": bool(np.array_equal(np.isnan(g), np.isnan(got)) and
+                                                                      np.array_equal(np.nan_to_num(g).view(np.uint32), np.nan_to_num(got).view(np.uint32)))}
+    clean = synth.make_case(args.config, null_frac=0.0)
+    ctx.set_images(clean.i0, clean.i1)
+    res = {}
+    for mode in ("auto", "u8px"):
+        ctx.set_path(mode)
+        leg.d_out.fill_(float("nan"))
+        el, km = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+        res[mode] = (el, km, ctx.last_path(), leg.d_out.cpu().numpy())
+    same = bool(np.array_equal(np.nan_to_num(res["auto"][3]).view(np.uint32), np.nan_to_num(res["u8px"][3]).view(np.uint32)))
+    out["null_free_pair"] = {"what": "the same grid on the pair without the zeroed blobs: every point on the matrix-core kernel's clean form",
+                             "ms_per_step": res["auto"][0] / args.steps * 1e3, "kernel_ms": res["auto"][1], "value": leg.n * args.steps / res["auto"][0],
+                             "kernel_path": res["auto"][2], "register_tiled_ms_per_step": res["u8px"][0] / args.steps * 1e3,
+                             "bit_identical_to_register_tiled": same}
+    ctx.set_images(case.i0, case.i1)
+    return out
+
+
+def passes_leg(torch, api, ctx, dev, case, xy):
+    """The 32 matcher passes of the program (MIMC_main.c:261-350: chip sizes 7 / 15 / 30 / 40 x raw, d/dx, d/dy, Laplacian x forward,
+    swapped), each timed on its own with HIP events on the resident pair: kernel path, ms, algorithmic bytes and the
+    fraction of the HBM roofline they amount to -- the program's seconds have a roofline of their own."""
+    H, W = case.i0.shape
+    stream = torch.cuda.current_stream()
+    d_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(dev)
+    d_out = torch.empty((xy.shape[0], 3), dtype=torch.float32, device=dev)
+    piv = {}
+    for ocw in (7, 15, 30, 40):
+        off, uv = api.get_uv_pivot(xy, case.dt, case.mpp, ocw, H, W)
+        piv[ocw] = (off, uv, api.pivot_extent(off, uv), torch.from_numpy(off).to(dev), torch.from_numpy(uv).to(dev), torch.from_numpy(np.ascontiguousarray(-uv)).to(dev),
+                    algorithmic_bytes(off, uv, ocw))
+    ctx.set_path("auto")
+    ctx.enable_timing(True)
+    out = []
+    for vi, variant in enumerate(("raw", "ddx", "ddy", "laplacian")):
+        ctx.filter_images(None if vi == 0 else api.CLI_KERNELS[vi - 1])
+        for ocw in (7, 15, 30, 40):
+            off, uv, ext, d_off, d_uv, d_uvn, alg = piv[ocw]
+            for swap in (False, True):
+                best = None
+                for _ in range(2):
+                    ctx.matching_ncc_dlc_2_dev(d_xy.data_ptr(), xy.shape[0], -case.offset if swap else case.offset, (d_uvn if swap else d_uv).data_ptr(),
+                                               d_off.data_ptr(), ext, ocw, d_out.data_ptr(), swap=swap, stream=stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    ms = ctx.last_kernel_ms()
+                    best = ms if best is None else min(best, ms)
+                ach = alg / (best * 1e-3) / 1e9
+                out.append({"variant": variant, "ocw": ocw, "direction": "swapped" if swap else "forward", "kernel_path": ctx.last_path(),
+                            "kernel": KERNEL_NAMES.get(ctx.last_path(), ctx.last_path()), "ms": best, "algorithmic_bytes": alg,
+                            "frac": ach / HBM_PEAK_GBS})
+    ctx.filter_images(None)
+    ctx.enable_timing(False)
     return out
 
 
