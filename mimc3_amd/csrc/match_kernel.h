@@ -35,7 +35,7 @@ constexpr int kCellGlobalGrid = 1024;   // persistent workgroups of the workspac
 size_t match_f32_workspace_bytes(int ocw, int max_abs_u, int max_abs_v, int max_npiv, int win_half);
 
 // ---- exact-integer path for 8-bit imagery (match_u8_kernel.hip) -------------------------------
-constexpr uint8_t kMxNulls = 2, kMxRest = 1;
+constexpr uint8_t kMxNulls = 2, kMxRest = 1, kMxWn = 3;
 constexpr int kU8Pad = 256;      // zero border (pixels) around the u8 planes; multiple of 4
 
 struct MatchU8Args {                // arguments of the register-tiled kernel family (match_px_kernel.hip)
@@ -60,7 +60,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     // form to its window-null form, kMxRest = neither form takes the point (plain stores: a shared list counter serialises ~100,000
     // same-address atomics per launch, measured 1.0 ms)
     uint8_t *mx_flags;
-    int32_t mx_gen_on;              // 0: the clean form hands points with nulls straight to the register-tiled kernel (kMxRest)
+    int32_t mx_gen_on, mx_wn_on;    // which of its forms for null-ridden points run behind the clean form (general / window nulls only); the others' points get kMxRest
     // flag mode of every kernel of the family: workgroup b handles point b only if point_flags[b] == flag_value
     const uint8_t *point_flags;
     int32_t flag_value;

@@ -66,10 +66,11 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 #undef MIMC3_MX_ARGMAX_STEP
 }
 
-template <int OCW_, bool GEN_>
+template <int OCW_, bool GEN_, bool CN_ = GEN_>
 struct Cfg {
     static constexpr int OCW = OCW_, CW = 2 * OCW_ + 1, NPX = CW * CW;
-    static constexpr bool GEN = GEN_;                   // the general form: null pixels in the window and / or in the chip
+    static constexpr bool GEN = GEN_;
+    static constexpr bool CN = CN_;                     // ... chips with nulls among them (false: the window-null form -- half the accumulators, a wave more per SIMD)                   // the general form: null pixels in the window and / or in the chip
     // Two waves per grid point: wave w owns the cell columns [16 w, 16 w + 16) of the 32 x 32 tile (two 16 x 16 MFMA tiles, rows
     // 0..15 and 16..31), so each wave carries half the accumulators.  The front phases run on both, the climb / replay / fit on wave 0
     // after wave 1 has left: registers per wave, not LDS, bound how many points a CU works on.
@@ -103,7 +104,7 @@ struct Cfg {
     static constexpr int OFF_RM = OFF_PIV + 512;       // general form: bit r = chip row r holds a null pixel
     static constexpr int LDS = OFF_RM + 16;
     static constexpr int WGS = 163840 / ((LDS + 255) & ~255);      // workgroups per CU that LDS admits
-    static constexpr int MINW0 = GEN_ ? 3 : 8;          // occupancy target, waves per SIMD (register budget) ...
+    static constexpr int MINW0 = GEN_ ? (CN_ ? 3 : 4) : 8;          // occupancy target, waves per SIMD (register budget) ...
     static constexpr int MINW1 = (WGS * NW) / 4 > 0 ? (WGS * NW) / 4 : 1;                   // ... never above what LDS admits anyway
     static constexpr int MINW = MINW0 < MINW1 ? MINW0 : MINW1;
 };
@@ -142,16 +143,24 @@ template <int CW, int KCW, int KCV> __device__ const Bands<CW, KCW, KCV> kBands{
 constexpr int kStatW = 8;
 
 // u8 pixels back from the signed bytes of an A operand, squared, split into the byte planes (x^2 & 255) and (x^2 >> 8), as signed bytes
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// the squares of the four pixels of a dword as the two byte planes (x^2 & 255, x^2 >> 8): the bytes spread to 16-bit halves (v_perm),
+// two packed 16-bit multiplies (a byte's square fits 16 bits), the planes picked out by v_perm -- 6 instructions
+__device__ __forceinline__ void squares_dword(uint32_t x, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t u01 = perm(0u, x, 0x0c010c00u), u23 = perm(0u, x, 0x0c030c02u);           // [b0, 0, b1, 0], [b2, 0, b3, 0]  (selector 0x0c: the byte 0)
+    const us2 p01 = __builtin_bit_cast(us2, u01), p23 = __builtin_bit_cast(us2, u23);
+    const uint32_t q01 = __builtin_bit_cast(uint32_t, (us2)(p01 * p01)), q23 = __builtin_bit_cast(uint32_t, (us2)(p23 * p23));
+    lo = perm(q23, q01, 0x06040200u);
+    hi = perm(q23, q01, 0x07050301u);
+}
 __device__ __forceinline__ void squares(const v4i &a, v4i &lo, v4i &hi)
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t x = (uint32_t)a[k] ^ 0x80808080u;
-        const uint32_t s0 = (x & 0xffu) * (x & 0xffu), s1 = ((x >> 8) & 0xffu) * ((x >> 8) & 0xffu);
-        const uint32_t s2 = ((x >> 16) & 0xffu) * ((x >> 16) & 0xffu), s3 = (x >> 24) * (x >> 24);
-        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);    // [s0.b0, s1.b0, s0.b1, s1.b1]
-        lo[k] = (int)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
-        hi[k] = (int)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+        uint32_t l, g;
+        squares_dword((uint32_t)a[k] ^ 0x80808080u, l, g);
+        lo[k] = (int)(l ^ 0x80808080u); hi[k] = (int)(g ^ 0x80808080u);
     }
 }
 // 0x80 (the signed byte -128) in every byte of an operand that is a null pixel (its signed byte is 0x80, i.e. the pixel 0; Toeplitz padding
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             const int t = tid + NT * (it0 + k);
             const int r = t / CD, j = t - CD * r;
             const bool on = (it0 + k < CNIT) && t < CTASK;
-            const uint32_t *g = cgb + (size_t)(on ? r : 0) * (Wp >> 2) + (on ? j : 0);
-            clo[k] = g[0]; chi[k] = g[1];
+            const uint32_t go = (uint32_t)(on ? r : 0) * (uint32_t)(Wp >> 2) + (uint32_t)(on ? j : 0);      // (32-bit offsets from a uniform base)
+            clo[k] = cgb[go]; chi[k] = cgb[go + 1u];
         }
     };
     chip_loads(0);
@@ -310,9 +319,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
             const int t = tid + NT * (it0 + k);
             const int y = t / NSEG, q = t - NSEG * y;
             const bool on = (it0 + k < TNIT) && t < TTASK;
-            const uint32_t *g = tgb + (size_t)(on ? y : 0) * (Wp >> 2) + 4 * (on ? q : 0);
+            const uint32_t go = (uint32_t)(on ? y : 0) * (uint32_t)(Wp >> 2) + 4u * (uint32_t)(on ? q : 0);
 #pragma unroll
-            for (int j = 0; j < 5; j++) td[k][j] = g[j];
+            for (int j = 0; j < 5; j++) td[k][j] = tgb[go + (uint32_t)j];
         }
     };
     tile_loads(0);
@@ -329,10 +338,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     const int chip_nulls = (int)(chipQ >> kSatNullShift8);
     const int win_nulls = __builtin_amdgcn_readfirstlane(win_nulls_v);
     if (npiv > 64 || !fits) { hand_on(kMxRest); return; }
-    if (!GEN && (win_nulls != 0 || chip_nulls != 0)) { hand_on(p.mx_gen_on ? kMxNulls : kMxRest); return; }
+    if (!GEN && (win_nulls != 0 || chip_nulls != 0)) {
+        hand_on((chip_nulls == 0 && p.mx_wn_on) ? kMxWn : (p.mx_gen_on ? kMxNulls : kMxRest));
+        return;
+    }
     // general form: wn = the written area of the window holds nulls (then the never-written last row / column are nulls like any other,
     // else they are applied in closed form as in the clean form); cn = the chip holds nulls
-    const bool wn = GEN && win_nulls != 0, cn = GEN && chip_nulls != 0;
+    const bool wn = GEN && win_nulls != 0, cn = C::CN && chip_nulls != 0;
 
     // ---- validity (a6, :605-644): nulls of the chip / of the whole Dy2 x Dx2 search area (its last row and column are never written: zeros)
     {
@@ -401,11 +413,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
                     const uint32_t m = (j == CD - 1) ? LASTM : 0xffffffffu;
                     *reinterpret_cast<uint32_t *>(CH + CH0 + CP * r + 4 * j) = (a ^ 0x80808080u) & m;
                     if (GEN && wn) {                          // the byte planes of a^2
-                        const uint32_t s0 = (a & 0xffu) * (a & 0xffu), s1 = ((a >> 8) & 0xffu) * ((a >> 8) & 0xffu);
-                        const uint32_t s2 = ((a >> 16) & 0xffu) * ((a >> 16) & 0xffu), s3 = (a >> 24) * (a >> 24);
-                        const uint32_t t01 = perm(s1, s0, 0x05010400u), t23 = perm(s3, s2, 0x05010400u);
-                        *reinterpret_cast<uint32_t *>(CH + C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x05040100u) ^ 0x80808080u) & m;
-                        *reinterpret_cast<uint32_t *>(CH + 2 * C::CHB + CH0 + CP * r + 4 * j) = (perm(t23, t01, 0x07060302u) ^ 0x80808080u) & m;
+                        uint32_t l, g;
+                        squares_dword(a, l, g);
+                        *reinterpret_cast<uint32_t *>(CH + C::CHB + CH0 + CP * r + 4 * j) = (l ^ 0x80808080u) & m;
+                        *reinterpret_cast<uint32_t *>(CH + 2 * C::CHB + CH0 + CP * r + 4 * j) = (g ^ 0x80808080u) & m;
                     }
                     if (GEN && cn) {                          // a null pixel (DN 0) among the dword's chip pixels: flag the chip row
                         const uint32_t nz = (((a & 0x7f7f7f7fu) + 0x7f7f7f7fu) | a) & 0x80808080u & m;
@@ -663,7 +674,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     //               reference's inf / NaN cases), is redone with the reference's own operations.  2^-15 of the cells; over 2^34 random
     //               cells the farthest one whose two results differed lay 7 ulps from its boundary.
     {
-        const int sx_col = 16 * wave + n, cx = tx0 + sx_col;
+        uint32_t tix = threadIdx.x;
+        asm volatile("" : "+v"(tix));                        // (formed again from the thread index: carried over from the header, it was the one register that spilled)
+        const int sx_col = (int)(tix >> 6) * 16 + (int)(tix & 15u), cx = tx0 + sx_col;
         // clean form, T4 in closed form: a cell whose box reaches the never-written last column (row) loses the chip's last column (row)
         uint32_t cS = (uint32_t)colQ & ((1u << kSatSqShift8) - 1u), cSS = (uint32_t)(colQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
         uint32_t rS = (uint32_t)rowQ & ((1u << kSatSqShift8) - 1u), rSS = (uint32_t)(rowQ >> kSatSqShift8) & ((1u << (kSatNullShift8 - kSatSqShift8)) - 1u);
@@ -753,31 +766,43 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
         su = pv.x + dx2; sv = pv.y + dy2;
     }
     const int start_u = su, start_v = sv;
+    // Lane k walks pivot k's climb on the complete surface, ignoring the visited state (which can only END a real climb earlier).  A scan's
+    // move and running maximum depend on NCC values alone, with the reference's compare sequence (:736-741): recorded as move deltas, 4 bits
+    // per scan ((du + 1) | (dv + 1) << 2; 5 = the scan did not move), plus one bit per scan "it raised the maximum".  Straight-line,
+    // predicated: one wave-uniform loop, no divergent control flow (the compiler's exec-mask bookkeeping for a per-lane `while` was half
+    // the loop's instructions).
     bool alive = lane < npiv && inside(su, sv);
     bool left = false;                                       // a scan would leave the tile
-    unsigned long long traj = 0ull;                          // 0 = no scan, 1..9 = the scan updated the maximum at 3x3 index code-1 (5 = centre), 10 = no update
+    uint32_t dlo = 0u, dhi = 0u, updm = 0u;
     int nsc = 0;
     {
         float smax = -2.0f;
-        while (alive && nsc < kSpecRounds) {
+#pragma unroll 1
+        for (int t = 0; t < kSpecRounds; t++) {
+            if (!__any(alive)) break;
             const int rx = relx(su), ry = rely(sv);
-            if (rx < 1 || rx > 30 || ry < 1 || ry > 30) { left = true; break; }
+            const bool in = (unsigned)(rx - 1) <= 29u && (unsigned)(ry - 1) <= 29u;
+            left = left || (alive && !in);
+            const bool act = alive && in;
+            const float *vp = val + (act ? ry : 1) * VP + (act ? rx : 1);          // (idle lanes read a harmless cell)
             float v[9];
 #pragma unroll
-            for (int j = 0; j < 9; j++) v[j] = val[(ry + (j % 3 - 1)) * VP + rx + (j / 3 - 1)];
+            for (int j = 0; j < 9; j++) v[j] = vp[(j % 3 - 1) * VP + (j / 3 - 1)];
             const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]), __builtin_fmaxf(__builtin_fmaxf(v[3], v[4]), v[5])),
                                             __builtin_fmaxf(__builtin_fmaxf(v[6], v[7]), v[8]));
-            int mv = -1;
-            if (m > smax) {
-                mv = 8;
+            uint32_t mv = 8u;
 #pragma unroll
-                for (int j = 7; j >= 0; j--) mv = (v[j] == m) ? j : mv;
-                smax = m;
-            }
-            const bool moved = (mv >= 0 && mv != 4);
-            if (moved) { su += mv / 3 - 1; sv += mv % 3 - 1; }
-            traj |= (unsigned long long)(mv >= 0 ? mv + 1 : 10) << (4 * nsc);
-            nsc++;
+            for (int j = 7; j >= 0; j--) mv = (v[j] == m) ? (uint32_t)j : mv;
+            const bool up = act && (m > smax);
+            smax = up ? m : smax;
+            const bool moved = up && mv != 4u;
+            const uint32_t q3 = (mv * 11u) >> 5;                                        // mv / 3 for 0..8
+            const uint32_t d = moved ? (q3 | ((mv - 3u * q3) << 2)) : 5u;
+            su += (int)(d & 3u) - 1; sv += (int)(d >> 2) - 1;
+            const uint32_t dsh = act ? d << (4 * (t & 7)) : 0u;
+            if (t < 8) dlo |= dsh; else dhi |= dsh;
+            updm |= (up ? 1u : 0u) << t;
+            nsc += act ? 1 : 0;
             alive = moved && inside(su, sv);
         }
     }
@@ -789,16 +814,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     int T = 0;
     uint32_t vrow = 0u;
     {
-        uint32_t dlo = 0u, dhi = 0u;                          // this lane's moves, 4 bits per scan: (du + 1) | (dv + 1) << 2; 5 = no move
-#pragma unroll
-        for (int t = 0; t < kSpecRounds; t++) {
-            if (__ballot(nsc > t) == 0ull) break;
-            const uint32_t code = (uint32_t)(traj >> (4 * t)) & 15u;
-            const bool moved = (code - 1u) < 9u && code != 5u;
-            const uint32_t mv = code - 1u, q3 = (mv * 11u) >> 5;
-            const uint32_t d = moved ? (q3 | ((mv - 3u * q3) << 2)) : 5u;
-            if (t < 8) dlo |= d << (4 * (t & 7)); else dhi |= d << (4 * (t & 7));
-        }
         const uint32_t head = (uint32_t)(relx(start_u) & 0xff) | ((uint32_t)(rely(start_v) & 0xff) << 8) | ((uint32_t)nsc << 16);
         for (int kk = 0; kk < npiv; kk++) {
             const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)head, kk);
@@ -843,11 +858,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     float best = -2.0f;
     {
         int fu = start_u, fv = start_v;
-        bool upd = false;
         for (int t = 0; t < T; t++) {
-            const int code = (int)((traj >> (4 * t)) & 15ull);
-            if (code <= 9) { const int mv = code - 1; const int q3 = (mv * 11) >> 5; fu += q3 - 1; fv += (mv - 3 * q3) - 1; upd = true; }
+            const uint32_t d = ((t < 8 ? dlo : dhi) >> (4 * (t & 7))) & 15u;
+            fu += (int)(d & 3u) - 1; fv += (int)(d >> 2) - 1;
         }
+        const bool upd = (updm & ((T >= 32 ? 0u : (1u << T)) - 1u)) != 0u;      // some scan among the T performed raised the maximum
         const uint32_t fpos = ((uint32_t)fv << 16) | (uint32_t)fu;
         const float fmax = upd ? val[rely(fv) * VP + relx(fu)] : -2.0f;
         float bv = (lane < npiv) ? fmax : -__builtin_inff();
@@ -940,7 +955,7 @@ static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
             free(hf);
         }
         fprintf(stderr, "[mimc3 mx stats] ocw %d %s: %zu points staged; cycles/point: stage %.0f products %.0f box sums %.0f ncc %.0f climb %.0f replay %.0f fit %.0f; lists so far: nulls %d rest %d\n",
-                C::OCW, C::GEN ? "general" : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
+                C::OCW, C::GEN ? (C::CN ? "general" : "window nulls") : "clean", live, hsum[0] / d, hsum[1] / d, hsum[2] / d, hsum[3] / d, hsum[4] / d, hsum[5] / d, hsum[6] / d, nn, nr);
     }
     return hipGetLastError();
 }
@@ -958,36 +973,41 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half, int max_abs_u, int 
     return ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40;
 }
 
-template <bool GEN>
+template <bool GEN, bool CN>
 static hipError_t launch_form(const MatchU8Args &a, hipStream_t stream)
 {
     switch (a.ocw) {
-    case 7: return mx::launch_one<mx::Cfg<7, GEN>>(a, stream);
-    case 15: return mx::launch_one<mx::Cfg<15, GEN>>(a, stream);
-    case 16: return mx::launch_one<mx::Cfg<16, GEN>>(a, stream);
-    case 30: return mx::launch_one<mx::Cfg<30, GEN>>(a, stream);
-    case 32: return mx::launch_one<mx::Cfg<32, GEN>>(a, stream);
-    case 40: return mx::launch_one<mx::Cfg<40, GEN>>(a, stream);
+    case 7: return mx::launch_one<mx::Cfg<7, GEN, CN>>(a, stream);
+    case 15: return mx::launch_one<mx::Cfg<15, GEN, CN>>(a, stream);
+    case 16: return mx::launch_one<mx::Cfg<16, GEN, CN>>(a, stream);
+    case 30: return mx::launch_one<mx::Cfg<30, GEN, CN>>(a, stream);
+    case 32: return mx::launch_one<mx::Cfg<32, GEN, CN>>(a, stream);
+    case 40: return mx::launch_one<mx::Cfg<40, GEN, CN>>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-// Two launches: the clean form over all points (or the caller's list), the general form over the points it flagged.  Points neither
+// Up to three launches: the clean form over all points (or the caller's list), then the forms for the points it flagged.  Points none
 // takes carry kMxRest in mx_flags afterwards.
 hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
 {
     if (a.N <= 0) return hipSuccess;
     if (!a.mx_flags || !a.sat0 || !a.sat1) return hipErrorInvalidValue;
-    // The general form (nulls on the matrix cores) is built, tested and bit-identical at every chip size, but it is not the default: at
-    // BASELINE C2 it costs 19 ns per null-ridden point at ocw 16 (the register-tiled kernel's sparse corrections: 18) and 86 ns at
-    // ocw 40 (66) -- its extra operand planes leave two to three workgroups per CU.  So the clean form takes the points without nulls
-    // (9 ns against 15 at ocw 16, 40 against 66 at ocw 40) and hands the others to that kernel; MIMC3_MX_GEN=1 turns the general form on.
+    // Which null-ridden points stay on the matrix cores: none by default.  Both forms for them are built, tested and bit-identical at
+    // every chip size, but measured at BASELINE C2 (ns per point; the register-tiled kernel's sparse corrections: 18 at ocw 16, 66 at
+    // ocw 40) the window-null form (null-free chip: four correlations) costs 16 and leaves that kernel the chip-null points alone, which
+    // it then runs at 23.5 -- 2.84 ms per pass against 2.75; the general form (chip nulls too: eight correlations) costs 19 at ocw 16
+    // and 86 at ocw 40, its operand planes leaving two to three workgroups per CU.  The clean form takes the points without nulls
+    // (8.9 ns against 11.3, 40 against 66 at ocw 40).  MIMC3_MX_WN / MIMC3_MX_GEN = 1 turn the other two on.
+    static const int wn_env = getenv("MIMC3_MX_WN") ? atoi(getenv("MIMC3_MX_WN")) : 0;
     static const int gen_env = getenv("MIMC3_MX_GEN") ? atoi(getenv("MIMC3_MX_GEN")) : 0;
+    a.mx_wn_on = wn_env > 0 ? 1 : 0;
     a.mx_gen_on = gen_env != 0 ? 1 : 0;
-    hipError_t e = launch_form<false>(a, stream);
-    if (e != hipSuccess || !a.mx_gen_on) return e;
-    a.point_flags = a.mx_flags; a.flag_value = kMxNulls;
-    return launch_form<true>(a, stream);
+    hipError_t e = launch_form<false, false>(a, stream);
+    a.point_flags = a.mx_flags;
+    if (e == hipSuccess && a.mx_wn_on) { a.flag_value = kMxWn; e = launch_form<true, false>(a, stream); }
+    if (e == hipSuccess && a.mx_gen_on) { a.flag_value = kMxNulls; e = launch_form<true, true>(a, stream); }
+    return e;
 }
 
 }  // namespace mimc3

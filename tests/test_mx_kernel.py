@@ -47,11 +47,12 @@ def test_every_chip_size_clean_and_with_nulls(api, oracle, ocw, null_frac):
         both_directions(api, ctx, c, off, uv, ocw, oracle, f"ocw {ocw} nulls {null_frac}")
 
 
+@pytest.mark.parametrize("forms", ["MIMC3_MX_GEN", "MIMC3_MX_WN", "both"])
 @pytest.mark.parametrize("ocw", MX_OCW)
-def test_general_form(ocw):
-    """The general form (window and chip nulls on the matrix cores) is not the default -- the register-tiled kernel takes the
-    null-ridden points: switched on, it must give the oracle's bits at every chip size (a subprocess: the switch is read once per
-    process)."""
+def test_forms_for_null_ridden_points(ocw, forms):
+    """The window-null form and the general form (window and chip nulls on the matrix cores) are not the default -- the register-tiled
+    kernel takes the null-ridden points: switched on, alone or together, they must give the oracle's bits at every chip size (a
+    subprocess: the switches are read once per process)."""
     code = textwrap.dedent("""
         import sys, numpy as np
         sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
@@ -72,7 +73,10 @@ def test_general_form(ocw):
             sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, ocw, swap=True)
             assert_bits_equal(sw, o.match(c.i1, c.i0, c.xyuvav, -c.offset, off, -uv, ocw), "general form swapped")
     """ % (ROOT, ROOT, ocw))
-    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, MIMC3_MX_GEN="1"))
+    env = dict(os.environ)
+    for k in (("MIMC3_MX_GEN", "MIMC3_MX_WN") if forms == "both" else (forms,)):
+        env[k] = "1"
+    subprocess.check_call([sys.executable, "-c", code], env=env)
 
 
 @pytest.mark.parametrize("angle", [45.0, -20.0, 100.0, 180.0])
