@@ -577,7 +577,8 @@ struct PxCfg {
     // The evaluation reads the chip from its LDS copy instead of registers (SPARSE configs keep that copy anyway): the u16
     // policy's 81-row chip is 52 dwords per lane next to a 42-dword window row in flight, which does not fit 128 or 168
     // VGPRs; from LDS the kernel runs at twice the occupancy without spills (the kernel is VALU-bound, LDS has headroom).
-    static constexpr bool CHIP_LDS = CHL_ && SPARSE;
+    static constexpr bool CHIP_LDS = CHL_;                   // (the f32 policies' chips too: 35 .. 83 dwords per lane next to f64 accumulators -- see launch_match_f32x)
+    static constexpr bool CHIP_COPY = SPARSE || CHIP_LDS;    // an LDS copy of the chip exists
     // Pivot sets of more than 64 (the 21x21 set of the control-point stage): the pivots beyond the first 64 have no lane of
     // their own; their speculative climbs are recorded in LDS so that the exact replay stays on the fast form.  A separate
     // instantiation: the plain configurations keep their register allocation.
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
                 else { bad_chip += P::nbad(a, pff, pt.thr); exc_chip += P::nexcl(a, pff, pt.thr); a = P::sanitize(a, pt.thr); }
                 A[i][j] = a;
                 if constexpr (!kSatChip) P::chip_acc(SX, SXX, a);
-                if constexpr (C::SPARSE) {
+                if constexpr (C::CHIP_COPY) {
                     if ((j % NW) == wave && rowok) *reinterpret_cast<uint32_t *>(CH + (l + C::LPC * i) * C::CPITCH + 4 * j) = a;   // every wave holds the whole chip: each writes a share of the copy
                 }
             }
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_px(MatchU8Args p
             toff[k] = rr * pt.PW + 4 * j;
             if (C::FULLTAIL && on && j == GPR - 1) padoff = toff[k];
             if constexpr (!kSatChip) P::chip_acc(SX, SXX, a);
-            if constexpr (C::SPARSE) {                     // tail rows: in the LDS copy (window nulls look chip values up there);
+            if constexpr (C::CHIP_COPY) {                  // tail rows: in the LDS copy (window nulls look chip values up there);
                 if ((k % NW) == wave && on) *reinterpret_cast<uint32_t *>(CH + rr * C::CPITCH + 4 * j) = a;   // their own nulls are masked by the tail tasks
             }
         }
@@ -2215,8 +2216,8 @@ static size_t px_layout(MatchU8Args *a, int max_abs_u, int max_abs_v, int max_np
     if (C::MANYP) {     // per pivot: 8 B trajectory + 1 B (scans recorded | still climbing << 7) + 1 B scans really performed
         off = (off + 15) & ~(size_t)15; r.lds_off_traj = (int)off; off += 10 * (size_t)max_npiv;
     }
+    if (C::CHIP_COPY) { off = (off + 15) & ~(size_t)15; r.lds_off_chip = (int)off; off += (size_t)C::CPITCH * C::CW; }
     if (C::SPARSE) {
-        off = (off + 15) & ~(size_t)15; r.lds_off_chip = (int)off; off += (size_t)C::CPITCH * C::CW;
         off = (off + 15) & ~(size_t)15; r.lds_off_lw = (int)off; off += (C::COMPACT ? 2 : 4) * (size_t)kLwCap;
         off = (off + 15) & ~(size_t)15; r.lds_off_lc = (int)off; off += (C::COMPACT ? 2 : 4) * (size_t)kLcCap;
     }
@@ -2316,19 +2317,25 @@ static hipError_t launch_pick(MatchU8Args a, int max_abs_u, int max_abs_v, int m
 
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
 {
-    if (!(ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 40)) return false;     // chip rows must fit the register image
+    if (!(ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40)) return false;     // chip rows must fit the register image
     return max_reach_u + 12 <= kU8Pad && max_reach_v + 12 <= kU8Pad && max_reach_u <= 120 && max_reach_v <= 120;
 }
 
 hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int max_npiv, hipStream_t stream)
 {
+    // The chip of these kernels stays in registers although several forms spill (integral ocw 15 / 16 / 40: 124 / 172 / 420 B of
+    // scratch per lane): read from an LDS copy instead (PxCfg::CHIP_LDS, no scratch at all, four waves per SIMD instead of three) the
+    // integral kernels measured 4.50 / 11.29 / 10.21 / 47.9 / 107.9 ms at ocw 7 / 15 / 16 / 30 / 40 on BASELINE C2's grid against
+    // 4.11 / 8.28 / 10.26 / 35.1 / 92.0 with the chip in registers -- the second LDS stream and the chunked row loop cost more than the
+    // spills do.  Only ocw 16 takes the LDS form (same time, no scratch traffic: 512 MB of writes per launch less).
     if (a.N <= 0 && !a.dry_run) return hipSuccess;
     if (a.sat0 && a.sat1) {        // integral 16-bit DN: the planes come with summed-area tables
         switch (a.ocw) {
         case 7: return launch_cfg<PxCfg<PxF32i, 7, 16, 2, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         case 15: return launch_cfg<PxCfg<PxF32i, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-        case 16: return launch_cfg<PxCfg<PxF32i, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 16: return launch_cfg<PxCfg<PxF32i, 16, 32, 2, 4, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         case 30: return launch_cfg<PxCfg<PxF32i, 30, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        case 32: return launch_cfg<PxCfg<PxF32i, 32, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         case 40: return launch_cfg<PxCfg<PxF32i, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
         default: return hipErrorInvalidValue;
         }
@@ -2338,6 +2345,7 @@ hipError_t launch_match_f32x(MatchU8Args a, int max_abs_u, int max_abs_v, int ma
     case 15: return launch_cfg<PxCfg<PxF32, 15, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxF32, 16, 32, 2, 3>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 30: return launch_cfg<PxCfg<PxF32, 30, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32: return launch_cfg<PxCfg<PxF32, 32, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 40: return launch_cfg<PxCfg<PxF32, 40, 64, 4, 2>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }

@@ -18,7 +18,7 @@ def api():
 U8_OCW = (7, 15, 16, 30, 32, 40)   # chip sizes the exact u8 kernel is instantiated for
 
 
-F32T_OCW = (7, 15, 16, 30, 40)      # chip sizes of the register-tiled f32 kernel
+F32T_OCW = (7, 15, 16, 30, 32, 40)     # chip sizes of the register-tiled f32 kernel
 
 
 def expected_path(mode, i0, ocw, i1=None):
