@@ -72,10 +72,12 @@ class Leg:
 
 def timed(torch, dist, world, dev, step, steps, warmup):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
-    Returns (seconds, mean ms between the HIP events recorded around the kernel launch of each step)."""
+    Returns (seconds, mean ms between the HIP events recorded around the kernel launch of each step, per-rank record):
+    at N > 1 the record holds every rank's own kernel time and the time of its exchange (a third event behind the all-gather),
+    so that a scaling line shows which rank and which part set the step."""
     for _ in range(warmup):
         step(None)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -90,7 +92,17 @@ def timed(torch, dist, world, dev, step, steps, warmup):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    per_rank = None
+    if world > 1:
+        gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+        mine = torch.tensor([kern_ms, gather_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = {"kernel_ms": [float(t[0].item()) for t in every], "all_gather_ms": [float(t[1].item()) for t in every],
+                    "what": "per rank, mean over the timed steps: HIP events around the matcher launch, and from there to behind the "
+                            "all-gather (which waits for the slowest rank's kernel)"}
+    return elapsed, kern_ms, per_rank
 
 
 def main():
@@ -176,12 +188,14 @@ def main():
                 ev[1].record(stream)
             if gather is not None:
                 gather(leg)
+                if ev is not None:
+                    ev[2].record(stream)
         return step
 
     result = {}
     if world == 1:
         leg = Leg(torch, api, dev, xy_all, piv_off, piv_uv, n_all)
-        elapsed, kern_ms = timed(torch, dist, world, dev, make_step(leg), args.steps, args.warmup)
+        elapsed, kern_ms, _ = timed(torch, dist, world, dev, make_step(leg), args.steps, args.warmup)
         alg_bytes = algorithmic_bytes(piv_off, piv_uv, case.ocw)
         n_job, n_rank0, scaling = n_all, n_all, "n/a"        # one rank: nothing scales
         got = leg.d_out.cpu().numpy()
@@ -200,7 +214,7 @@ def main():
             g = shard.all_gather_blocks(leg.d_out, per, world)                 # the ONE exchange: [world][per][3]
             field["full"] = to_grid(g)                                         # grid order, on every rank
 
-        el_s, km_s = timed(torch, dist, world, dev, make_step(leg_s, gather_strong), args.steps, args.warmup)
+        el_s, km_s, pr_s = timed(torch, dist, world, dev, make_step(leg_s, gather_strong), args.steps, args.warmup)
         # ---- weak: every rank its own lattice of the config's size (lattice r shifted r px in x: an N-times denser grid)
         xy_w = xy_all.copy()
         xy_w[:, 2] += rank; xy_w[:, 0] += rank * case.mpp
@@ -210,12 +224,12 @@ def main():
         def gather_weak(leg):
             field["weak"] = shard.all_gather_blocks(leg.d_out, n_all, world)
 
-        el_w, km_w = timed(torch, dist, world, dev, make_step(leg_w, gather_weak), args.steps, args.warmup)
+        el_w, km_w, pr_w = timed(torch, dist, world, dev, make_step(leg_w, gather_weak), args.steps, args.warmup)
         strong = {"value": n_all * args.steps / el_s, "ms_per_step": el_s / args.steps * 1e3, "kernel_ms_rank0": km_s,
-                  "grid_points_rank0": int(leg_s.n), "points_per_step": n_all, "work_imbalance": imb,
+                  "grid_points_rank0": int(leg_s.n), "points_per_step": n_all, "work_imbalance": imb, "per_rank": pr_s,
                   "what": f"{args.config}'s {n_all} points in cost-balanced shares of {shard.default_block(n_all, world)}-point blocks"}
         weak = {"value": n_all * world * args.steps / el_w, "ms_per_step": el_w / args.steps * 1e3, "kernel_ms_rank0": km_w,
-                "grid_points_rank0": n_all, "points_per_step": n_all * world,
+                "grid_points_rank0": n_all, "points_per_step": n_all * world, "per_rank": pr_w,
                 "what": f"every rank its own {n_all}-point lattice (shifted r px), all-gather of [{world}][{n_all}][3]"}
         result["strong"], result["weak"] = strong, weak
         if args.scaling == "strong":
@@ -351,7 +365,7 @@ def f32_leg(torch, dist, dev, ctx, leg, make_step, piv_off, piv_uv, case, args, 
     """The same C2 workload forced onto the register-tiled f32 kernel (f32 products, f64 sums): what a 16-bit pair gets."""
     ctx.set_path("f32")
     leg.d_out.fill_(float("nan"))
-    elapsed, kern_ms = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+    elapsed, kern_ms, _ = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
     alg = algorithmic_bytes(piv_off, piv_uv, case.ocw)
     ach = alg / (kern_ms * 1e-3) / 1e9
     out = {"kernel_path": ctx.last_path(), "value": leg.n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
@@ -375,7 +389,7 @@ def kernel_legs(torch, dist, dev, api, synth, ctx, leg, make_step, piv_off, piv_
     out = {}
     ctx.set_path("u8px")
     leg.d_out.fill_(float("nan"))
-    el, km = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+    el, km, _ = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
     g = leg.d_out.cpu().numpy()
     out["register_tiled_alone"] = {"kernel_path": ctx.last_path(), "ms_per_step": el / args.steps * 1e3, "kernel_ms": km, "value": leg.n * args.steps / el,
                                    "bit_identical_to_headline": bool(np.array_equal(np.isnan(g), np.isnan(got)) and
@@ -386,7 +400,7 @@ def kernel_legs(torch, dist, dev, api, synth, ctx, leg, make_step, piv_off, piv_
     for mode in ("auto", "u8px"):
         ctx.set_path(mode)
         leg.d_out.fill_(float("nan"))
-        el, km = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
+        el, km, _ = timed(torch, dist, 1, dev, make_step(leg), args.steps, 2)
         res[mode] = (el, km, ctx.last_path(), leg.d_out.cpu().numpy())
     same = bool(np.array_equal(np.nan_to_num(res["auto"][3]).view(np.uint32), np.nan_to_num(res["u8px"][3]).view(np.uint32)))
     out["null_free_pair"] = {"what": "the same grid on the pair without the zeroed blobs: every point on the matrix-core kernel's clean form",
