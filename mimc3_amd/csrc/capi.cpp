@@ -1388,6 +1388,9 @@ extern "C" int mimc3_get_offset_image_multi(mimc3_ctx *const *ctxs, int32_t nctx
         if (!ctxs[r]) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: a context is NULL");
         if (!ctxs[r]->raw_i0 || !ctxs[r]->raw_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: images not set");
         if (ctxs[r]->H != c->H || ctxs[r]->W != c->W) return mimc3::fail(MIMC3_ESTATE, "mimc3_get_offset_image: the contexts hold different image pairs");
+        // (a context listed twice would have two host threads slicing on the same scratch, children and streams)
+        for (int32_t q = 0; q < r; q++)
+            if (ctxs[q] == ctxs[r]) return mimc3::fail(MIMC3_EINVAL, "mimc3_get_offset_image: a context is listed twice");
     }
     for (int k = 0; k < 3; k++)
         if (!p->kernel[k] || p->kdim[k][0] < 1 || p->kdim[k][0] > 3 || p->kdim[k][1] < 1 || p->kdim[k][1] > 3)

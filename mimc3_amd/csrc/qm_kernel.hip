@@ -203,13 +203,15 @@ __global__ __launch_bounds__(kQmFinishThreads) void qm_finish_sweep(QmArgs a, in
     // the block's words -> its own slots (device scope: the last block may sit on another XCD, behind another L2)
     if ((int)threadIdx.x < nw)
         __hip_atomic_store(reinterpret_cast<unsigned int *>(&a.diff[threadIdx.x * gridDim.x + blockIdx.x]), sh[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // acknowledged before the ticket below is taken
-    __syncthreads();
+    __syncthreads();                                                     // (workgroup scope: the slot stores above happen-before thread 0's release)
+    // the ticket: release publishes this block's slots (and, transitively through the barrier, every thread's), acquire in the
+    // block that draws the last ticket makes every other block's slots visible to it -- no hand-written wait counts
     if (threadIdx.x == 0)
-        sh[kQmMaskWords] = __hip_atomic_fetch_add(&a.flags[kQmTicket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1u : 0u;
+        sh[kQmMaskWords] = __hip_atomic_fetch_add(&a.flags[kQmTicket], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!sh[kQmMaskWords]) return;
     // ---- the last block: OR of every block's words, then qm_decide
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // every thread of the last block reads other blocks' slots
     __syncthreads();
     if (threadIdx.x < kQmMaskWords) sh[threadIdx.x] = 0u;
     __syncthreads();

@@ -67,6 +67,9 @@ def test_slices_over_several_contexts(api, oracle, name, peers):
         for c in ctxs:
             c.set_images(i0, i1)
         st, o2, f2, info2, sduv2 = ctxs[0].get_offset_image(xy, K, seed=5, num_cp_min=20, peers=ctxs[1:])
+        # a context listed twice is refused (two host threads would slice on the same scratch and streams)
+        with pytest.raises(api.Mimc3Error):
+            ctxs[0].get_offset_image(xy, K, seed=5, num_cp_min=20, peers=[ctxs[1], ctxs[1]] if peers > 1 else [ctxs[0]])
         # a peer that holds another pair is refused, not used
         ctxs[-1].set_images(i0[:-8], i1[:-8])
         with pytest.raises(api.Mimc3Error):
