@@ -346,7 +346,9 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
     pout = api.pinned_empty((n, 3), np.float32)
     dt_cor, got = run(lambda: ctx.matching_ncc_dlc_cor(pxy, pcor, case.offset, case.ocw, out=pout))
     got = np.array(got)
-    dt_geo, _ = run(lambda: ctx.matching_ncc_dlc_geo(pxy, case.offset, case.dt, case.mpp, case.ocw))
+    pout2 = api.pinned_empty((n, 3), np.float32)
+    dt_geo, got_geo = run(lambda: ctx.matching_ncc_dlc_geo(pxy, case.offset, case.dt, case.mpp, case.ocw, out=pout2))
+    same_geo = bool(np.array_equal(np.asarray(got_geo).view(np.uint32), got.view(np.uint32)))
     dt_csr, _ = run(lambda: ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw))
     same = bool(np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)))
     return {"value": n / dt_cor, "ms_per_step": dt_cor * 1e3, "steps": steps,
@@ -354,7 +356,7 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
             "identical_to_resident_run": same,
             "what": "mimc3_match_ncc_dlc_cor: per grid point 16 B of (u, v) + 24 B of corridor up, pivot lists made on the device, kernel, 12 B down; "
                     "three chunks, transfers under the matcher; pair resident, corridors made beforehand (as the csr form's lists are)",
-            "with_host_corridors_inside": {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3,
+            "with_host_corridors_inside": {"value": n / dt_geo, "ms_per_step": dt_geo * 1e3, "identical": same_geo,
                                            "what": "mimc3_match_ncc_dlc_geo: + atan2 / cos / sin of every point on the host threads inside the step"},
             "csr_upload_form": {"value": n / dt_csr, "ms_per_step": dt_csr * 1e3,
                                 "bytes_over_pcie_per_step": int(pxy.nbytes + puv.nbytes + poff.nbytes + 12 * n),

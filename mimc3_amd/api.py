@@ -387,11 +387,13 @@ class Context:
                                         ocw, 1 if swap else 0, out), "matching_ncc_dlc_2")
         return out
 
-    def matching_ncc_dlc_geo(self, xyuvav, offset, dt, mpp, ocw, swap=False, aw_sf=1.8, aw_cre=10.0):
-        """get_uv_pivot + matching_ncc_dlc_2 in one call: corridors from the host, pivot lists made on the device.
-        swap=True = the swapped pass (images exchanged, pivots negated; the caller negates offset and (du, dv))."""
+    def matching_ncc_dlc_geo(self, xyuvav, offset, dt, mpp, ocw, swap=False, aw_sf=1.8, aw_cre=10.0, out=None):
+        """get_uv_pivot + matching_ncc_dlc_2 in one call: corridors from the host (made chunk by chunk under the device's work), pivot
+        lists made on the device.  swap=True = the swapped pass (images exchanged, pivots negated; the caller negates offset and
+        (du, dv)).  `out` may be a pinned array (as for matching_ncc_dlc_cor)."""
         xy = np.ascontiguousarray(xyuvav, np.float64)
-        out = np.empty((xy.shape[0], 3), np.float32)
+        if out is None:
+            out = np.empty((xy.shape[0], 3), np.float32)
         _check(_lib.mimc3_match_ncc_dlc_geo(self._h, xy, xy.shape[0], np.ascontiguousarray(offset, np.int32), dt, mpp, aw_sf, aw_cre, ocw,
                                             1 if swap else 0, out), "matching_ncc_dlc_geo")
         return out

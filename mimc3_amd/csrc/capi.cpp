@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -774,8 +775,10 @@ extern "C" int mimc3_get_uv_pivot_dev(mimc3_ctx *c, const double *d_xyuvav, cons
 // grid point: its (u, v) (16 B: the matcher and the pivot kernel read nothing else of an xyuvav row), its corridor (24 B), its
 // result (12 B).  The grid goes through in chunks: uploads + pivot counts on one copy stream, lists + matcher on the context's
 // stream, downloads on a second copy stream -- the transfers of chunk k+1 / k-1 run under the matcher of chunk k.
-extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const void *cor, int32_t N, const int32_t offset[2], int32_t ocw,
-                                       int32_t swap, float *out)
+// `produce`, when given, fills cor[g0, g1) on the host right before that chunk is packed and sent: the corridors of chunk k+1 are
+// made (threaded libm work) while the device matches chunk k
+static int match_cor_impl(mimc3_ctx *c, const double *xyuvav, const void *cor, int32_t N, const int32_t offset[2], int32_t ocw,
+                          int32_t swap, float *out, const std::function<void(int32_t, int32_t)> *produce)
 {
     if (!c || !xyuvav || !cor || !offset || !out || N <= 0) return mimc3::fail(MIMC3_EINVAL, "mimc3_match_ncc_dlc_cor: bad argument");
     if (!c->d_i0 || !c->d_i1) return mimc3::fail(MIMC3_ESTATE, "mimc3_match_ncc_dlc_cor: images not set");
@@ -825,6 +828,7 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
     //      (u, v) + corridors up, pivot counts + offsets, the 24 bytes that size lists and launch back
     auto upload = [&](int k) -> int {
         const size_t g0 = (size_t)lo[k], n = (size_t)(lo[k + 1] - lo[k]);
+        if (produce) (*produce)(lo[k], lo[k + 1]);
         for (int32_t g = lo[k]; g < lo[k + 1]; ++g) {
             const double gu = xyuvav[6 * (size_t)g + 2], gv = xyuvav[6 * (size_t)g + 3];
             const int32_t u0 = (int32_t)gu, v0 = (int32_t)gv;
@@ -882,6 +886,8 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
         return 0;
     };
     // chunk k+1 is packed and sent off before chunk k's matcher is enqueued: the device never waits for the host's loop
+    // (the same order with `produce`: enqueuing chunk k's matcher BEFORE making chunk k+1's corridors measured 3.78 ms per pass against
+    // 3.35 -- the matcher's enqueue waits for the chunk's list sizes to come back, and that wait is where the host has time to spare)
     rc = upload(0);
     for (int k = 0; k < K && !rc; k++) {
         if (k + 1 < K) rc = upload(k + 1);
@@ -897,7 +903,13 @@ extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const
     return 0;
 }
 
-// the same with the corridors made here (the libm half of get_uv_pivot: threaded host code)
+extern "C" int mimc3_match_ncc_dlc_cor(mimc3_ctx *c, const double *xyuvav, const void *cor, int32_t N, const int32_t offset[2], int32_t ocw,
+                                       int32_t swap, float *out)
+{
+    return match_cor_impl(c, xyuvav, cor, N, offset, ocw, swap, out, nullptr);
+}
+
+// the same with the corridors made here (the libm half of get_uv_pivot: threaded host code), chunk by chunk under the device's work
 extern "C" int mimc3_match_ncc_dlc_geo(mimc3_ctx *c, const double *xyuvav, int32_t N, const int32_t offset[2], float dt, float mpp, float aw_sf,
                                        float aw_cre, int32_t ocw, int32_t swap, float *out)
 {
@@ -905,8 +917,11 @@ extern "C" int mimc3_match_ncc_dlc_geo(mimc3_ctx *c, const double *xyuvav, int32
     HIP_TRY(hipSetDevice(c->device));
     void *hcor = nullptr;
     RC_TRY(mimc3_ctx_host_workspace(c, 7, sizeof(mimc3::CorridorPOD) * (size_t)N, &hcor));      // pinned, kept across calls
-    mimc3::pivot_corridors(xyuvav, N, dt, mpp, aw_sf, aw_cre, static_cast<mimc3::CorridorPOD *>(hcor));
-    return mimc3_match_ncc_dlc_cor(c, xyuvav, hcor, N, offset, ocw, swap, out);
+    mimc3::CorridorPOD *hc = static_cast<mimc3::CorridorPOD *>(hcor);
+    const std::function<void(int32_t, int32_t)> produce = [&](int32_t g0, int32_t g1) {
+        mimc3::pivot_corridors(xyuvav + 6 * (size_t)g0, g1 - g0, dt, mpp, aw_sf, aw_cre, hc + g0);
+    };
+    return match_cor_impl(c, xyuvav, hcor, N, offset, ocw, swap, out, &produce);
 }
 
 // ---------------------------------------------------------------------------------------------

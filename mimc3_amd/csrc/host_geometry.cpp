@@ -98,7 +98,10 @@ public:
 private:
     Pool()
     {
+        // (16 threads at most: a GPU's share of a node's cores; hardware_concurrency() reports the whole node)
         unsigned hw = std::thread::hardware_concurrency();
+        const char *env = getenv("MIMC3_HOST_THREADS");                      // tuning
+        if (env && atoi(env) >= 1) hw = (unsigned)atoi(env); else if (hw > 16) hw = 16;
         workers_ = (int)(hw > 64 ? 64 : hw) - 1;
         if (workers_ < 0) workers_ = 0;
         for (int i = 0; i < workers_; i++) std::thread([this] { loop(); }).detach();
