@@ -310,7 +310,7 @@ int mimc3_vmap_passes_points(mimc3_ctx *ctx, const double *xs, int32_t n, float 
  *      (1) one process per GPU (torch.distributed / MPI launchers): mimc3_vmap_passes + the caller's own all-gather +
  *          mimc3_vmap_finish, above;
  *      (2) ONE process driving several GPUs, here: a host thread per device and an RCCL communicator over them
- *          (ncclCommInitAll; RCCL is loaded with dlopen on first use -- env MIMC3_RCCL_LIB overrides librccl.so.1).
+ *          (ncclCommInitAll; RCCL -- librccl.so.1 -- is loaded with dlopen on first use).
  *          The MIMC3_hip command line takes this form with MIMC3_HIP_DEVICES=0,1,...
  *      Shares are cost-balanced: mimc3_point_cost adds (4 + 6 npiv)(2 ocw + 1)^2 per point (NCC evaluations x chip area),
  *      mimc3_partition_points cuts the grid into blocks of `block` consecutive points, deals them heaviest-first to the

@@ -1,31 +1,35 @@
 // match_mx_kernel.hip -- DLC/NCC matcher for gfx950 on the matrix cores: 8-bit imagery, DENSE correlation surfaces.
 //
 // Same contract as match_px_kernel.hip (matching_ncc_dlc_2, MIMC_module.c:805-842), for the points whose reachable cell grid
-// fits one 32 x 32 tile.  One wave64 = one grid point.  Instead of evaluating the cells a hill climb asks for (a request
-// queue, evaluation batches, a speculative climb that waits for them), the kernel builds the COMPLETE surface of the tile:
+// fits one 32 x 32 tile.  One workgroup of two wave64 = one grid point (wave w owns the cell columns [16 w, 16 w + 16)).  Instead of
+// evaluating the cells a hill climb asks for (a request queue, evaluation batches, a speculative climb that waits for them), the
+// kernel builds the COMPLETE surface of the tile:
 //
 //   sxy[dy][s] = sum_r sum_k a[r][k] * b[r + dy][k + s]                              (MIMC_module.c:719-733, the product stream)
-//              = sum_r (W_r T_r)[dy][s]     W_r[dy][j] = b[r + dy][j]   A operand: 32 window rows, plain 16-byte LDS reads
+//              = sum_r (W_r T_r)[dy][s]     W_r[dy][j] = b[r + dy][j]   A operand: 16 window rows, plain 16-byte LDS reads
 //                                           T_r[j][s]  = a[r][j - s]    B operand: the Toeplitz band of chip row r, 0 outside
-//   i.e. one v_mfma_i32_32x32x32_i8 per chip row and 32 window columns, all into ONE 32 x 32 i32 accumulator (exact integers).
-//   u8 -> i8:  a' = a - 128 (a ^ 0x80), b' = b - 128, Toeplitz padding a' = 0:
+//   i.e. per chip row, 64 window columns and 16 x 16 cells one v_mfma_i32_16x16x64_i8, all into the cells' i32 accumulators (exact
+//   integers).  u8 -> i8:  a' = a - 128 (a ^ 0x80), b' = b - 128, Toeplitz padding a' = 0:
 //              sum ab = sum a'b' + 128 sum_box b + 128 sum a - 128^2 CW^2        (a null is a zero factor: no mask anywhere)
 //   * window-side sums  sy = sum_box b, syy = sum_box b^2  of every cell: row-box sums by MFMA against a band of ones
 //     (b^2 as two byte planes), then the vertical CW-row sums by a second MFMA against a band of ones (the row sums split
 //     into byte planes; an accumulator tile is the next MFMA's B operand as it stands: its rows are the K index);
-//   * null pixels (general form).  A window null q of the box takes a(q) out of n, sx, sxx: with zb = [b == 0] as the A operand the
-//     corrections are three more correlations on the same pipe -- sum zb (box count), sum a zb (same B operand as sxy), sum a^2 zb
-//     (a^2 as two byte planes, formed from the B operand in registers).  A chip null p takes b(p) out of sy, syy: with za = [a == 0]
-//     as the B operand -- formed from the Toeplitz rows of the chip rows that hold nulls, the only ones visited -- sum b za,
-//     sum b^2 za (b^2 as two byte planes of the A operand), and sum zb za for n.  The never-written last window row / column (T4) are
-//     zeros of the staged tile, i.e. nulls like any other when the window's nulls are correlated anyway; otherwise (and in the clean
-//     form) they are applied in closed form: they take the chip's last column / row out of n, sx, sxx;
-//   * the NCC of all 1,024 cells (:734, f64, no contraction) -> one f32 surface in LDS;
+//   * null pixels (the two forms for null-ridden points, built and tested but not taken by default: launch_match_mx has the
+//     measurements).  A window null q of the box takes a(q) out of n, sx, sxx: with zb = [b == 0] as the A operand the corrections
+//     are three more correlations on the same pipe -- sum zb (box count), sum a zb (same B operand as sxy), sum a^2 zb (a^2 as two
+//     byte planes of the chip) -- the window-null form.  A chip null p takes b(p) out of sy, syy: with za = [a == 0] as the B operand
+//     -- formed from the Toeplitz rows of the chip rows that hold nulls, the only ones visited -- sum b za, sum b^2 za (b^2 as two
+//     byte planes of the A operand), and sum zb za for n -- the general form.  The never-written last window row / column (T4) are
+//     zeros of the staged tile, i.e. nulls like any other when the window's nulls are correlated anyway; in the clean form they are
+//     applied in closed form: they take the chip's last column / row out of n, sx, sxx (table queries of the chip plane);
+//   * the NCC of all 1,024 cells (:734, f64, no contraction; a guarded fast reciprocal square root with the exact sqrt / division
+//     for the cells within 2^13 f64 ulps of an f32 rounding boundary) -> one f32 surface in LDS;
 //   * the climb of every pivot on the complete surface (lane k = pivot k), the exact replay of the reference's sequential
-//     visited-set semantics (:691-753) and the 3x3 fit (:757-788) as in match_px_kernel.hip.
-// What this kernel does not take it hands on (device lists, no host round trip): points whose window holds nulls go from the
-// clean form to the general form; more than 64 pivots, pivot sets wider than the tile, climbs that leave the
-// tile or outlast the 16 recorded scans go to the register-tiled kernel (match_px_kernel.hip) in list mode.
+//     visited-set semantics (:691-753) and the 3x3 fit (:757-788) as in match_px_kernel.hip -- on wave 0, wave 1 has left by then.
+// What this kernel does not take it hands on through a flag byte per grid point (no host round trip, no shared counter: same-address
+// atomics of 100,000 points serialise into a millisecond): a point with nulls in its window or chip, more than 64 pivots, a pivot
+// set wider than the tile, a climb that leaves the tile or outlasts the 16 recorded scans is flagged for the register-tiled kernel
+// (match_px_kernel.hip), which runs right behind in flag mode (or for this kernel's other forms, when they are switched on).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <mutex>
@@ -69,8 +73,8 @@ __device__ __forceinline__ void argmax_row16(float &v, int &i)
 template <int OCW_, bool GEN_, bool CN_ = GEN_>
 struct Cfg {
     static constexpr int OCW = OCW_, CW = 2 * OCW_ + 1, NPX = CW * CW;
-    static constexpr bool GEN = GEN_;
-    static constexpr bool CN = CN_;                     // ... chips with nulls among them (false: the window-null form -- half the accumulators, a wave more per SIMD)                   // the general form: null pixels in the window and / or in the chip
+    static constexpr bool GEN = GEN_;                   // null pixels in the window ...
+    static constexpr bool CN = CN_;                     // ... and in the chip (false with GEN: the window-null form -- half the accumulators, a wave more per SIMD)
     // Two waves per grid point: wave w owns the cell columns [16 w, 16 w + 16) of the 32 x 32 tile (two 16 x 16 MFMA tiles, rows
     // 0..15 and 16..31), so each wave carries half the accumulators.  The front phases run on both, the climb / replay / fit on wave 0
     // after wave 1 has left: registers per wave, not LDS, bound how many points a CU works on.

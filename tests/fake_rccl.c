@@ -4,11 +4,11 @@
  * Why it exists: the GPU test box has ONE device, and RCCL refuses a communicator that lists a device twice, so the
  * N > 1 branches of the native multi-GPU driver (a host thread per rank, padded blocks with world > 1, the grouped
  * all-gather issued from one thread, the un-permute over several ranks' blocks) could never run there.  With
- * MIMC3_RCCL_LIB=<this library> and MIMC3_MGPU_ALLOW_REPEAT=1 the driver runs N ranks as N contexts (N streams) of
+ * mimc3_mgpu_create_ex(devices, n, <this library>, MIMC3_MGPU_REPEAT_DEVICES, ...) the driver runs N ranks as N contexts (N streams) of
  * the same device, and the "collective" below moves the blocks with device-to-device copies ordered by events:
  *     recv[r][k * count .. (k+1) * count) = send[k][0 .. count)      for every rank r and k
  * which is exactly what ncclAllGather produces.  What it does NOT test is xGMI transport: that needs a real node
- * (run tests/test_mgpu.py there with MIMC3_TEST_DEVICES=0,1,... and without these two variables).
+ * (run tests/test_mgpu.py there with MIMC3_TEST_DEVICES=0,1,...: the plain mimc3_mgpu_create).
  *
  * Build: gcc -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/fake_rccl.c -L/opt/rocm/lib -lamdhip64
  * Not part of the product; nothing under mimc3_amd/ refers to it. */
