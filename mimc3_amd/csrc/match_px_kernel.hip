@@ -2315,6 +2315,24 @@ static hipError_t launch_pick(MatchU8Args a, int max_abs_u, int max_abs_v, int m
     return launch_cfg<CD>(a, max_abs_u, max_abs_v, max_npiv, stream);
 }
 
+// Big chips whose windows leave LDS for more than four workgroups per CU (BASELINE C2's geometry at ocw 30 / 32: six / five) run faster
+// at a higher occupancy target although the smaller register budget spills (measured on C2's grid, ms per pass at 4 / 5 / 6 waves per
+// SIMD: u8 ocw 30 10.59 / 9.38 / 8.98, ocw 32 10.82 / 9.70 / 11.90, u8o ocw 30 14.26 / 13.07 / 13.97, ocw 32 14.58 / 13.58 / 16.43; ocw 40,
+// the u16 kernels and the ocw-7 kernels lose: profiles/round4/kbench_occupancy_target_sweep_big_chips.txt).  CH = the same
+// configuration at that target; it is taken when the launch's LDS need admits as many workgroups, else the four-wave form (or its
+// compact variant) as before.
+template <class CD, class CH>
+static bool lds_admits_high(const MatchU8Args &a, int max_abs_u, int max_abs_v, int max_npiv)
+{
+    static const int off = getenv("MIMC3_HIGH_OCC") ? atoi(getenv("MIMC3_HIGH_OCC")) : 1;      // tuning / A-B: 0 = never
+    static const bool forced_form = getenv("MIMC3_COMPACT") != nullptr;                          // tests force an LDS form: launch_pick's business
+    if (!off || forced_form) return false;
+    MatchU8Args t = a;
+    const size_t b = px_layout<CD>(&t, max_abs_u, max_abs_v, max_npiv);
+    const size_t g = (b + 255) & ~(size_t)255;
+    return g != 0 && (int)(kLdsCapBytes / g) >= CH::MINW;
+}
+
 bool match_f32x_supported(int ocw, int max_reach_u, int max_reach_v)
 {
     if (!(ocw == 7 || ocw == 15 || ocw == 16 || ocw == 30 || ocw == 32 || ocw == 40)) return false;     // chip rows must fit the register image
@@ -2385,8 +2403,14 @@ hipError_t launch_match_u8o(MatchU8Args a, int max_abs_u, int max_abs_v, int max
     case 7: return launch_cfg<PxCfg<PxU8o, 7, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 15: return launch_cfg<PxCfg<PxU8o, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU8o, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 30: return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_cfg<PxCfg<PxU8o, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30:
+        if (lds_admits_high<PxCfg<PxU8o, 30, 64, 4, 4>, PxCfg<PxU8o, 30, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv))
+            return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        return launch_cfg<PxCfg<PxU8o, 30, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32:
+        if (lds_admits_high<PxCfg<PxU8o, 32, 64, 4, 4>, PxCfg<PxU8o, 32, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv))
+            return launch_cfg<PxCfg<PxU8o, 32, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        return launch_cfg<PxCfg<PxU8o, 32, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 40: return launch_cfg<PxCfg<PxU8o, 40, 64, 4, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
@@ -2473,8 +2497,14 @@ hipError_t launch_match_u8(MatchU8Args a, int max_abs_u, int max_abs_v, int max_
     case 15: return launch_cfg<PxCfg<PxU8, 15, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 16: return launch_cfg<PxCfg<PxU8, 16, 16, 1, 4>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     // big chips: 4 waves share one point's LDS image (one cell per wave and round)
-    case 30: return launch_pick<PxCfg<PxU8, 30, 64, 4, 4>, PxCfg<PxU8, 30, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
-    case 32: return launch_pick<PxCfg<PxU8, 32, 64, 4, 4>, PxCfg<PxU8, 32, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 30:
+        if (lds_admits_high<PxCfg<PxU8, 30, 64, 4, 4>, PxCfg<PxU8, 30, 64, 4, 6>>(a, max_abs_u, max_abs_v, max_npiv))
+            return launch_cfg<PxCfg<PxU8, 30, 64, 4, 6>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        return launch_pick<PxCfg<PxU8, 30, 64, 4, 4>, PxCfg<PxU8, 30, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+    case 32:
+        if (lds_admits_high<PxCfg<PxU8, 32, 64, 4, 4>, PxCfg<PxU8, 32, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv))
+            return launch_cfg<PxCfg<PxU8, 32, 64, 4, 5>>(a, max_abs_u, max_abs_v, max_npiv, stream);
+        return launch_pick<PxCfg<PxU8, 32, 64, 4, 4>, PxCfg<PxU8, 32, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     case 40: return launch_pick<PxCfg<PxU8, 40, 64, 4, 4>, PxCfg<PxU8, 40, 64, 4, 4, false, false, true>>(a, max_abs_u, max_abs_v, max_npiv, stream);
     default: return hipErrorInvalidValue;
     }
