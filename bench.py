@@ -267,6 +267,9 @@ def main():
             "h2d_images": {"raw_dn_pinned_s": t_h2d_raw, "f32_pageable_s": t_h2d_f32,
                            "note": "pair upload incl. device-side widening + plane build; raw = 1 B/px as the 8-bit TIFF holds it"},
         }
+        if path == "u8_mfma":
+            res["roofline"]["launches"] = ("two launches per step, timed together: match_ncc_dlc_mx (the points without null pixels in reach whose corridors fit its "
+                                           "32 x 32-cell tile; it flags the others), then match_ncc_dlc_px<PxU8> in flag mode for the flagged points")
         res.update(result)
         try:   # counters of this kernel from rocprofv3 PMC passes of this same command (tools/profile.sh + tools/pmc_to_json.py)
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[args.config][kname]

@@ -152,7 +152,7 @@ def test_c4_shape_2048_all_points(api, checker):
     want = checker.match(i0, i1, xy, zero, off, uv, 32)
     with api.Context(0) as ctx:
         ctx.set_images(i0, i1)
-        for mode, path in (("auto", "u8_exact"), ("u16", "u16_scaled"), ("general", "general_f32")):      # (31 pivots: wider than the matrix-core kernel's tile)
+        for mode, path in (("auto", "u8_mfma"), ("u8px", "u8_exact"), ("u16", "u16_scaled"), ("general", "general_f32")):      # (31 pivots: wider than the matrix-core kernel's tile -- every point passes through it and is flagged)
             ctx.set_path(mode)
             got = ctx.matching_ncc_dlc_2(xy, zero, off, uv, 32)
             assert ctx.last_path() == path
@@ -171,7 +171,7 @@ def test_c4_full_size_sampled_vs_reference(api, checker):
     with api.Context(0) as ctx:
         ctx.set_images(c.i0, c.i1)
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
-        assert ctx.last_path() == "u8_exact"
+        assert ctx.last_path() == "u8_mfma"            # (the matrix-core kernel flags every point: corridors wider than its tile)
     idx = np.unique(np.linspace(0, c.n - 1, 60000).astype(np.int64))
     soff, suv = subset(off, uv, idx)
     want = checker.match(c.i0, c.i1, np.ascontiguousarray(c.xyuvav[idx]), c.offset, soff, suv, c.ocw)

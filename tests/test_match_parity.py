@@ -385,6 +385,7 @@ def test_long_corridor_big_chip_falls_back_when_lds_is_short(api, oracle, reach,
         got = ctx.matching_ncc_dlc_2(c.xyuvav, c.offset, off, uv, c.ocw)
         path = ctx.last_path()
         sw = ctx.matching_ncc_dlc_2(c.xyuvav, -c.offset, off, -uv, c.ocw, swap=True)
+    # ((60, "auto"): more than 64 pivots per point -- not a launch the matrix-core kernel takes)
     expect = {(60, "auto"): "u8_exact", (60, "u8px"): "u8_exact", (100, "u8px"): "general_f32", (60, "u16"): "general_f32", (60, "f32"): "general_f32", (60, "general"): "general_f32",
               (100, "auto"): "general_f32", (100, "u16"): "general_f32", (100, "f32"): "general_f32", (100, "general"): "general_f32"}
     assert path == expect[(reach, mode)]

@@ -95,6 +95,30 @@ def test_tiles_that_do_not_cover_the_cell_grid(api, oracle, speed, angle):
         both_directions(api, ctx, c, off, uv, 16, oracle, f"speed {speed} angle {angle}")
 
 
+@pytest.mark.parametrize("ocw", [7, 16])
+def test_a_few_fast_points_among_slow_ones(api, oracle, ocw):
+    """A velocity field with a few fast points (corridors of 35+ pivots: wider than the tile) among slow ones: the launch's longest
+    corridor does not decide for the launch -- the kernel flags the fast points one by one for the register-tiled kernel (whose LDS
+    carve is sized by them) and keeps the slow ones."""
+    c = synth.make_small(seed=6200 + ocw, shift=(3, -4), angle_deg=-50.0, ocw=ocw, speed=1600.0, h=420, w=430, dimx=7, dimy=7,
+                         noise_dn=2, null_frac=0.02, margin=130)
+    xy = c.xyuvav.copy()
+    xy[::9, 4:6] *= 3.4                                       # every ninth point 3.4 times as fast
+    H, W = c.i0.shape
+    off, uv = api.get_uv_pivot(xy, c.dt, c.mpp, ocw, H, W)
+    last = np.abs(uv[off[1:] - 1]).max(axis=1)
+    assert last.max() > 29 and np.median(last) <= 20, (last.max(), np.median(last))
+    with api.Context(0) as ctx:
+        ctx.set_images(c.i0, c.i1)
+        got = ctx.matching_ncc_dlc_2(xy, c.offset, off, uv, ocw)
+        assert ctx.last_path() == "u8_mfma"
+        assert_bits_equal(got, oracle.match(c.i0, c.i1, xy, c.offset, off, uv, ocw), "mixed field")
+        sw = ctx.matching_ncc_dlc_2(xy, -c.offset, off, -uv, ocw, swap=True)
+        assert_bits_equal(sw, oracle.match(c.i1, c.i0, xy, -c.offset, off, -uv, ocw), "mixed field, swapped")
+        ctx.set_path("u8px")
+        assert_bits_equal(ctx.matching_ncc_dlc_2(xy, c.offset, off, uv, ocw), got, "register-tiled alone")
+
+
 def test_points_at_the_image_edge_and_void_windows(api, oracle):
     """Windows that hang over the image edge (zeros outside, :877-884), points whose search area is more than 80 % void (-3),
     a chip with a single null pixel, a window whose only nulls are its never-written last row and column."""
