@@ -973,7 +973,7 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half, int max_abs_u, int 
     if (win_half > 0) return false;                   // full-square search areas (control-point stage): many pivots, not this kernel
     // A point whose pivots (with the ring of cells their first scans touch) do not fit the 32 x 32 tile is flagged for the
     // register-tiled kernel by the kernel itself, point by point: a velocity field with a few fast points keeps its slow ones here.
-    // (A launch whose every corridor is too long -- BASELINE C4: 31 pivots -- only passes through: 0.3 ns per point.)  The launch's
+    // (A launch whose every corridor is too long -- BASELINE C4: 31 pivots -- only passes through: 3 ns per point at ocw 32, 158.0 -> 161.1 ms.)  The launch's
     // maxima still size the register-tiled kernel's LDS carve, as without this kernel.
     (void)max_abs_u; (void)max_abs_v;
     if (max_npiv > 64) return false;                  // (the many-pivot kernel forms: no tables)
