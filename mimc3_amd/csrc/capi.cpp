@@ -635,6 +635,7 @@ extern "C" int mimc3_match_ncc_dlc_dev(mimc3_ctx *c, const double *d_xyuvav, int
                 HIP_TRY(ml.reserve((size_t)N));
                 HIP_TRY(hipMemsetAsync(ml.p, 0, (size_t)N, s));
                 u.mx_flags = static_cast<uint8_t *>(ml.p);
+                u.mx_preflag = (max_abs_piv_u > 29 || max_abs_piv_v > 29) ? 1 : 0;      // some corridors may be wider than the kernel's tile
                 e = mimc3::launch_match_mx(u, s);
                 if (e == hipSuccess) {
                     u.point_flags = u.mx_flags; u.flag_value = mimc3::kMxRest;

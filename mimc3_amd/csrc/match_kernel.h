@@ -60,6 +60,7 @@ struct MatchU8Args {                // arguments of the register-tiled kernel fa
     // form to its window-null form, kMxRest = neither form takes the point (plain stores: a shared list counter serialises ~100,000
     // same-address atomics per launch, measured 1.0 ms)
     uint8_t *mx_flags;
+    int32_t mx_preflag;             // the launch may hold corridors wider than the tile: a pre-pass has flagged those points (kMxRest), the kernel leaves them at once
     int32_t mx_gen_on, mx_wn_on;    // which of its forms for null-ridden points run behind the clean form (general / window nulls only); the others' points get kMxRest
     // flag mode of every kernel of the family: workgroup b handles point b only if point_flags[b] == flag_value
     const uint8_t *point_flags;

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     }
     if (gidx >= p.N) return;
     if (p.point_flags && p.point_flags[gidx] != (uint8_t)p.flag_value) return;      // flag mode: the points another kernel handed over
+    if (p.mx_preflag && p.mx_flags[gidx] == kMxRest) return;                         // flagged by mx_preflag_kernel: corridor wider than the tile
     auto hand_on = [&](uint8_t to) __attribute__((always_inline)) {
         if (tid == 0) p.mx_flags[gidx] = to;
     };
@@ -922,6 +923,28 @@ __global__ __launch_bounds__(C::NT, C::MINW) void match_ncc_dlc_mx(MatchU8Args p
     MIMC3_MX_STATS_OUT
 }
 
+// Pre-pass for launches whose longest corridor exceeds the tile (one thread per grid point): flags the points the kernel below would
+// hand on for that reason -- the same placement test as in its header -- so that they cost it one byte load instead of a header's
+// two memory round trips (BASELINE C4, where every point is such a point: 161.1 -> 159.9 ms per pass).
+__global__ __launch_bounds__(256) void mx_preflag_kernel(MatchU8Args p)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.N) return;
+    const int64_t pbeg = p.piv_off[g];
+    const int npiv = (int)(p.piv_off[g + 1] - pbeg);
+    if (npiv < 1) return;
+    const int OCW = p.ocw;
+    const int lu = p.piv_uv[2 * (pbeg + npiv - 1)], lv = p.piv_uv[2 * (pbeg + npiv - 1) + 1];
+    const int dx2 = (lu < 0 ? -lu : lu) + OCW + 2, dy2 = (lv < 0 ? -lv : lv) + OCW + 2;
+    const int csx = 2 * dx2 + 1 - 2 * OCW + 1, csy = 2 * dy2 + 1 - 2 * OCW + 1;
+    bool fits = true;
+    const int c0x = dx2 - OCW, c1x = c0x + lu, c0y = dy2 - OCW, c1y = c0y + lv;
+    const int lox = min(c0x, c1x), hix = max(c0x, c1x), loy = min(c0y, c1y), hiy = max(c0y, c1y);
+    if (csx - 2 > 32) { const int tx0 = min(max((lox + hix) / 2 - 15, 1), csx - 2 - 31); fits = fits && lox - 1 >= tx0 && hix + 1 <= tx0 + 31; }
+    if (csy - 2 > 32) { const int ty0 = min(max((loy + hiy) / 2 - 15, 1), csy - 2 - 31); fits = fits && loy - 1 >= ty0 && hiy + 1 <= ty0 + 31; }
+    if (npiv > 64 || !fits) p.mx_flags[g] = kMxRest;
+}
+
 template <class C>
 static hipError_t launch_one(MatchU8Args a, hipStream_t stream)
 {
@@ -973,7 +996,8 @@ bool match_mx_supported(int ocw, int max_npiv, int win_half, int max_abs_u, int 
     if (win_half > 0) return false;                   // full-square search areas (control-point stage): many pivots, not this kernel
     // A point whose pivots (with the ring of cells their first scans touch) do not fit the 32 x 32 tile is flagged for the
     // register-tiled kernel by the kernel itself, point by point: a velocity field with a few fast points keeps its slow ones here.
-    // (A launch whose every corridor is too long -- BASELINE C4: 31 pivots -- only passes through: 3 ns per point at ocw 32, 158.0 -> 161.1 ms.)  The launch's
+    // (A launch whose every corridor is too long -- BASELINE C4: 31 pivots -- only passes through: mx_preflag_kernel marks such points
+    // beforehand and the kernel leaves them after one byte load; 158.0 -> 159.9 ms per pass at C4, 161.1 without the pre-pass.)  The launch's
     // maxima still size the register-tiled kernel's LDS carve, as without this kernel.
     (void)max_abs_u; (void)max_abs_v;
     if (max_npiv > 64) return false;                  // (the many-pivot kernel forms: no tables)
@@ -1010,6 +1034,7 @@ hipError_t launch_match_mx(MatchU8Args a, hipStream_t stream)
     static const int gen_env = getenv("MIMC3_MX_GEN") ? atoi(getenv("MIMC3_MX_GEN")) : 0;
     a.mx_wn_on = wn_env > 0 ? 1 : 0;
     a.mx_gen_on = gen_env != 0 ? 1 : 0;
+    if (a.mx_preflag) hipLaunchKernelGGL(mx::mx_preflag_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, stream, a);
     hipError_t e = launch_form<false, false>(a, stream);
     a.point_flags = a.mx_flags;
     if (e == hipSuccess && a.mx_wn_on) { a.flag_value = kMxWn; e = launch_form<true, false>(a, stream); }
