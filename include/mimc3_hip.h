@@ -69,10 +69,10 @@ int mimc3_ctx_set_images_dev(mimc3_ctx *ctx, const float *d_i0, const float *d_i
  *   4 = the u8 kernel read through per-point offsets, for INTEGER images of kind 3 whose values stay within an
  *       8-bit range locally (the gradient filters of 8-bit images); the few points whose chip or window does
  *       not fit are redone by kernel 3 right behind.  Exact like 3 (same integer sums, rebuilt from q - k);
- *   2 = register-tiled f32 kernel (any f32 imagery, e.g. 16-bit DN) when ocw is one of 7, 15, 16, 30, 40;
- *   5 = the matrix-core form of kernel 1 (dense correlation surfaces on v_mfma_i32_32x32x32_i8), taken first for the
- *       chip sizes it is built for; the points it does not take (chips with nulls, corridors wider than its 32 x 32 cell
- *       tile, ...) are redone by kernel 1 right behind;
+ *   2 = register-tiled f32 kernel (any f32 imagery, e.g. 16-bit DN) when ocw is one of 7, 15, 16, 30, 32, 40;
+ *   5 = the matrix-core form of kernel 1 (dense correlation surfaces on v_mfma_i32_16x16x64_i8), taken first for the
+ *       chip sizes it is built for; the points it does not take (null pixels in the window or chip, corridors wider than
+ *       its 32 x 32 cell tile, ...) are flagged and done by kernel 1 right behind;
  *   0 = general f32 kernel (any ocw, any window size) otherwise.
  * All three give results bit-identical to the reference on integral-DN data.  mode 1 forces kernel 0,
  * mode 2 skips the integer kernels, mode 3 skips only the u8 kernel, mode 4 is mode 0 without kernel 5 (tests use
