@@ -853,9 +853,15 @@ static int match_cor_impl(mimc3_ctx *c, const double *xyuvav, const void *cor, i
     int64_t uv_base = 0;
     const int32_t keep_stride = c->xy_stride, keep_col = c->xy_col;
     c->xy_stride = 2; c->xy_col = 0;
+    // chunks alternate between two streams (and two sets of per-call scratch: c->lane), so that the first launches of chunk k+1 run
+    // under the tail of chunk k's last one
+    static const int two_env = getenv("MIMC3_IO_TWO_STREAMS") ? atoi(getenv("MIMC3_IO_TWO_STREAMS")) : 1;      // tuning / A-B
+    const bool two = two_env != 0 && K > 1 && c->aux[2] != nullptr;
     auto process = [&](int k) -> int {
         const size_t g0 = (size_t)lo[k];
         const int32_t n = lo[k + 1] - lo[k];
+        hipStream_t s = (two && (k & 1)) ? c->aux[2] : c->stream;
+        c->lane = (two && (k & 1)) ? 1 : 0;
         hipError_t e = hipEventSynchronize(c->ev_chunk[0][k]);
         if (e != hipSuccess) { rc = mimc3::hip_fail(e, "chunk upload"); return rc; }
         const int32_t *h = hext + 16 * k;
@@ -864,7 +870,8 @@ static int match_cor_impl(mimc3_ctx *c, const double *xyuvav, const void *cor, i
         if (h[3]) { rc = mimc3::fail(MIMC3_EBOUNDS, "mimc3_match_ncc_dlc_cor: a grid point has zero pivots (too close to the image edge)"); return rc; }
         if ((size_t)(uv_base + total) > uv_cap) {
             // the lists of this chunk do not fit behind the earlier ones: let those finish, then start over in a bigger buffer
-            e = hipStreamSynchronize(s);
+            e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess && two) e = hipStreamSynchronize(c->aux[2]);
             if (e != hipSuccess) { rc = mimc3::hip_fail(e, "pivot lists"); return rc; }
             uv_cap = 2 * (size_t)total > uv_cap ? 2 * (size_t)total + 2 * (size_t)(N - lo[k]) * 24 : 2 * uv_cap;
             e = c->puv.reserve(8 * uv_cap);
@@ -874,6 +881,10 @@ static int match_cor_impl(mimc3_ctx *c, const double *xyuvav, const void *cor, i
         int32_t *uv = static_cast<int32_t *>(c->puv.p) + 2 * uv_base;
         const int64_t *off = static_cast<const int64_t *>(c->poff.p) + g0 + k;
         e = hipStreamWaitEvent(s, c->ev_chunk[0][k], 0);
+        // (the general kernel's global cell workspace -- windows that outgrow LDS altogether -- is one per context: such a chunk waits
+        //  for its predecessor on the other stream)
+        if (e == hipSuccess && two && k > 0 && mimc3::match_f32_workspace_bytes(ocw, h[1], h[2], h[0], c->win_half) != 0)
+            e = hipStreamWaitEvent(s, c->ev_chunk[1][k - 1], 0);
         if (e == hipSuccess) e = mimc3::launch_pivot_fill(reinterpret_cast<const mimc3::CorridorDev *>(d_cor) + g0, off, n, swap ? nullptr : uv, swap ? uv : nullptr, s);
         if (e != hipSuccess) { rc = mimc3::hip_fail(e, "pivot lists"); return rc; }
         float *d_out = static_cast<float *>(c->out.p) + 3 * g0;
@@ -895,9 +906,11 @@ static int match_cor_impl(mimc3_ctx *c, const double *xyuvav, const void *cor, i
         if (!rc) rc = process(k);
     }
     c->xy_stride = keep_stride; c->xy_col = keep_col;
+    c->lane = 0;
     lap("chunks enqueued");
     // every stream drains before the buffers are reused (also on the error paths)
     hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(s), e3 = hipStreamSynchronize(down);
+    if (two) { const hipError_t e4 = hipStreamSynchronize(c->aux[2]); if (e2 == hipSuccess) e2 = e4; }
     lap("drained");
     if (rc) return rc;
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return mimc3::hip_fail(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "mimc3_match_ncc_dlc_cor");
