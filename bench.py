@@ -338,11 +338,15 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
     poff = api.pinned_empty(piv_off.shape, np.int64); poff[:] = piv_off
 
     def run(fn):
-        fn()
-        t0 = time.perf_counter()
+        # every call is a complete host-to-host pass (synchronous): timed one by one, the MEDIAN of the steps is reported -- a host
+        # hiccup in one of ten steps (seen: one 11 ms step among 3 ms ones) would otherwise decide the figure
+        fn(); fn()
+        ts = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             out = fn()
-        return (time.perf_counter() - t0) / steps, out
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), out
 
     cor = api.pivot_corridors(xy, case.dt, case.mpp)                  # the libm half of get_uv_pivot: made beforehand, like the lists of the csr form
     pcor = api.pinned_empty(cor.shape, np.uint8); pcor[:] = cor
@@ -354,7 +358,7 @@ def io_leg(api, ctx, case, xy, piv_off, piv_uv, steps, want):
     same_geo = bool(np.array_equal(np.asarray(got_geo).view(np.uint32), got.view(np.uint32)))
     dt_csr, _ = run(lambda: ctx.matching_ncc_dlc_2(pxy, case.offset, poff, puv, case.ocw))
     same = bool(np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)))
-    return {"value": n / dt_cor, "ms_per_step": dt_cor * 1e3, "steps": steps,
+    return {"value": n / dt_cor, "ms_per_step": dt_cor * 1e3, "steps": steps, "statistic": "median of the steps (each a synchronous host-to-host call)",
             "bytes_over_pcie_per_step": int((16 + api.CORRIDOR_BYTES + 12) * n + 4 * 24),
             "identical_to_resident_run": same,
             "what": "mimc3_match_ncc_dlc_cor: per grid point 16 B of (u, v) + 24 B of corridor up, pivot lists made on the device, kernel, 12 B down; "

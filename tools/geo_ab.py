@@ -16,7 +16,7 @@ with api.Context(0) as ctx:
             ts = []
             for _ in range(20):
                 t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-            print(name, "median %.3f min %.3f ms" % (np.median(ts) * 1e3, np.min(ts) * 1e3), flush=True)
+            print(name, "median %.3f min %.3f mean %.3f max %.3f ms" % (np.median(ts) * 1e3, np.min(ts) * 1e3, np.mean(ts) * 1e3, np.max(ts) * 1e3), flush=True)
     t0 = time.perf_counter()
     for _ in range(10): api.pivot_corridors(c.xyuvav, c.dt, c.mpp)
     print("corridors alone %.3f ms" % ((time.perf_counter() - t0) * 100), flush=True)
